@@ -1,0 +1,194 @@
+/*
+ * orbx.h -- C ABI of the MI355X ORB front end (extractor + Hamming matcher).
+ *
+ * Every entry point takes plain pointers and sizes.  Return value: 0 = ok, negative = error
+ * (see orbx_strerror).  Citations name the interface of the reference (lianbin/orbslam2) that
+ * the entry point replaces, as file:line relative to the reference root.
+ *
+ * Threading: a handle is not re-entrant (one call at a time per handle, like one
+ * ORBextractor instance); different handles may be used concurrently from different threads
+ * (the reference runs the left and right extractor in two std::threads, src/Frame.cc:79-82).
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- errors */
+enum {
+    ORBX_OK = 0,
+    ORBX_E_ARG = -1,       /* null pointer, non-positive size, unsupported parameter */
+    ORBX_E_HIP = -2,       /* a HIP runtime call failed (orbx_last_hip_error has the code) */
+    ORBX_E_CAPACITY = -3,  /* caller buffer or handle workspace too small */
+    ORBX_E_GEOMETRY = -4,  /* image too tall for the quadtree: round(width/height) of a level is 0
+                              (the reference divides by zero there, src/ORBextractor.cc:584-589) */
+    ORBX_E_NODEVICE = -5,  /* no usable GPU */
+    ORBX_E_STATE = -6      /* call order violated (no batch extracted yet, ...) */
+};
+const char *orbx_strerror(int code);
+int orbx_last_hip_error(void);
+/* library version (major*10000 + minor*100 + patch) */
+int orbx_version(void);
+
+/* ---------------------------------------------------------------- extractor */
+
+/* Constructor arguments of ORB_SLAM2::ORBextractor (include/ORBextractor.h:51-52,
+ * src/ORBextractor.cc:432-506) plus the workspace bounds of this implementation. */
+typedef struct orbx_params {
+    int nfeatures;      /* ORBextractor.nFeatures */
+    float scale_factor; /* ORBextractor.scaleFactor */
+    int nlevels;        /* ORBextractor.nLevels (1..16) */
+    int ini_th_fast;    /* ORBextractor.iniThFAST */
+    int min_th_fast;    /* ORBextractor.minThFAST */
+    int blur_variant;   /* 0: 7x7 sigma-2 kernel 18,34,48,56,48,34,18 /256 (OpenCV >= 3.4.1 fixed point);
+                           1: 18,34,49,55,49,34,18 /256 saturating (OpenCV 2.4 / <= 3.4.0) */
+    int max_width;      /* largest image the handle will see */
+    int max_height;
+    int max_batch;      /* largest number of frames per batch call (>= 1) */
+    int device;         /* HIP device ordinal */
+} orbx_params;
+
+/* Same memory layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id):
+ * 28 bytes, so a std::vector<cv::KeyPoint> can be filled with one memcpy. */
+typedef struct orbx_keypoint {
+    float x, y;     /* level-0 pixel coordinates (level coordinate * scale factor of the octave) */
+    float size;     /* (int)(31 * scale) */
+    float angle;    /* degrees, [0,360) */
+    float response; /* FAST score */
+    int32_t octave;
+    int32_t class_id; /* always -1 */
+} orbx_keypoint;
+
+typedef struct orbx_extractor orbx_extractor;
+
+/* replaces ORBextractor::ORBextractor (src/ORBextractor.cc:432-506).  Allocates all device
+ * workspaces for max_batch frames of max_width x max_height. */
+int orbx_extractor_create(const orbx_params *params, orbx_extractor **out);
+void orbx_extractor_destroy(orbx_extractor *ex);
+
+/* Work is enqueued on this stream (a hipStream_t; NULL = the handle's own stream). */
+int orbx_extractor_set_stream(orbx_extractor *ex, void *hip_stream);
+
+/* replaces GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:63-83); each array has nlevels entries. */
+int orbx_extractor_levels(const orbx_extractor *ex);
+int orbx_extractor_scale_tables(const orbx_extractor *ex, float *scale, float *inv_scale, float *sigma2,
+                                float *inv_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:460-475), nlevels entries */
+int orbx_extractor_features_per_level(const orbx_extractor *ex, int *quota);
+/* upper bound of keypoints one frame can produce (sum over levels of quota+3, at least 4*nIni) */
+int orbx_extractor_max_keypoints(const orbx_extractor *ex);
+
+/* replaces ORBextractor::operator() (src/ORBextractor.cc:1114-1182) for one host image:
+ * uploads, extracts, downloads, synchronises.  image: height rows of stride_bytes, 8-bit gray.
+ * keypoints/descriptors: caller buffers for cap entries (cap*28 and cap*32 bytes); *n_out receives
+ * the number of keypoints (rows of descriptors), level-major, in-level order = quadtree list order.
+ * An empty image (NULL or zero size) returns ORBX_OK with *n_out = -1 and the outputs untouched,
+ * as the reference returns early (:1117-1118).  ORBX_E_CAPACITY if cap is too small (nothing
+ * written except *n_out = required count). */
+int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride_bytes,
+                 orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n_out);
+
+/* Throughput form: batch frames already resident in device memory (frame f starts at
+ * d_images + f*frame_stride_bytes).  Asynchronous on the handle's stream; results stay in the
+ * handle's device buffers until the next batch call.  The images must stay valid and unchanged
+ * until the stream has finished the batch. */
+int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int batch, int width, int height,
+                              int stride_bytes, int64_t frame_stride_bytes);
+/* Same, frames in host memory (uploaded with one async copy per frame). */
+int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const *images, int batch, int width, int height,
+                            int stride_bytes);
+
+/* Blocks until the last batch is finished and returns the per-frame keypoint counts
+ * (batch entries) and, if not NULL, the per-level counts (batch*nlevels).  A negative return
+ * reports a device-side failure of the batch (ORBX_E_CAPACITY / ORBX_E_GEOMETRY). */
+int orbx_batch_counts(orbx_extractor *ex, int *n_per_frame, int *n_per_level);
+/* Downloads the keypoints and descriptors of one frame of the last batch. */
+int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *keypoints, uint8_t *descriptors, int cap,
+                        int *n_out);
+/* Device addresses of the result arrays of the last batch: keypoints (frame f at
+ * +f*max_keypoints entries), descriptors (32 bytes each, same indexing), per-frame counts. */
+int orbx_batch_device_results(orbx_extractor *ex, const orbx_keypoint **d_keypoints, const uint8_t **d_descriptors,
+                              const int32_t **d_counts, int *max_keypoints);
+
+/* replaces reads of the public member mvImagePyramid (include/ORBextractor.h:85; read by
+ * src/Frame.cc:541,631,643,648): copies level `level` of frame `frame` of the last batch into
+ * dst (dst_stride bytes per row; dst may be NULL to query the size).  border > 0 additionally
+ * writes a BORDER_REFLECT_101 frame of that many pixels around it, dst then points at the
+ * top-left of the padded buffer of (w+2*border) x (h+2*border) (the reference keeps border 19,
+ * src/ORBextractor.cc:1199-1219). */
+int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, int border, uint8_t *dst, int dst_stride,
+                       int *width, int *height);
+
+/* Stage outputs of the last batch, for parity tests.  what: 0 = FAST/NMS score map of a level
+ * (u8, level-sized, 0 where the pixel is not a per-cell local maximum), 1 = blurred level. */
+int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int level, uint8_t *dst, int dst_stride);
+/* Candidate list of a level before the quadtree (src/ORBextractor.cc:880-890): coordinates
+ * relative to (16,16), reference order.  Returns the count through *n_out. */
+int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, int *xs, int *ys, int *resp, int cap,
+                          int *n_out);
+
+/* ---------------------------------------------------------------- matcher */
+
+/* replaces ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1744-1760): Hamming distance of two
+ * 256-bit descriptors.  Pure host function, thread-safe, never touches the GPU. */
+int orbx_descriptor_distance(const uint8_t *a, const uint8_t *b);
+
+/* ORBmatcher::TH_HIGH / TH_LOW / HISTO_LENGTH (src/ORBmatcher.cc:37-39) */
+#define ORBX_TH_HIGH 100
+#define ORBX_TH_LOW 50
+#define ORBX_HISTO_LENGTH 30
+
+typedef struct orbx_matcher orbx_matcher;
+int orbx_matcher_create(int device, int max_queries, orbx_matcher **out);
+void orbx_matcher_destroy(orbx_matcher *m);
+int orbx_matcher_set_stream(orbx_matcher *m, void *hip_stream);
+
+/* Brute-force top-2 of every query against a descriptor database (shard), the inner loop of
+ * ORBmatcher::SearchByBoW (src/ORBmatcher.cc:217-242) over a flat candidate list: best and
+ * second-best start at 256, strict '<' updates in database order (first index wins ties).
+ * best_idx = idx_base + row of the best entry, or -1 when the shard is empty.
+ * Device form: all pointers are device addresses, asynchronous on the matcher's stream. */
+int orbx_match_top2_device(orbx_matcher *m, const uint8_t *d_queries, int nq, const uint8_t *d_db, int64_t ndb,
+                           int64_t idx_base, int32_t *d_best_idx, uint16_t *d_d1, uint16_t *d_d2);
+/* Host form: uploads queries and database, runs, downloads, synchronises. */
+int orbx_match_top2(orbx_matcher *m, const uint8_t *queries, int nq, const uint8_t *db, int64_t ndb,
+                    int64_t idx_base, int32_t *best_idx, uint16_t *d1, uint16_t *d2);
+
+/* Merges per-shard top-2 results (nshards arrays of nq entries, shard s at offset s*nq, shards in
+ * ascending index order) into the result of one pass over the concatenated database. Host function. */
+int orbx_top2_merge(int nshards, int nq, const int32_t *best_idx, const uint16_t *d1, const uint16_t *d2,
+                    int32_t *out_idx, uint16_t *out_d1, uint16_t *out_d2);
+/* Acceptance rule of src/ORBmatcher.cc:245-249: d1 <= th && (float)d1 < ratio*(float)d2.
+ * accept[i] = 1/0; returns the number accepted. Host function. */
+int orbx_ratio_test(int nq, const uint16_t *d1, const uint16_t *d2, int th, float ratio, uint8_t *accept);
+
+/* replaces ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:433-549) with the candidate
+ * windows of Frame::GetFeaturesInArea (src/Frame.cc:349-407) over the 64x48 grid of
+ * Frame::AssignFeaturesToGrid (src/Frame.cc:239-253).  Host keypoints/descriptors of both frames;
+ * (min_x,max_x,min_y,max_y) are Frame::mnMinX.. (image bounds); prev_matched holds n1 (x,y) pairs,
+ * read and updated (vbPrevMatched); matches12 receives n1 indices into frame 2 or -1.
+ * The window distances are computed on the GPU, the order-dependent greedy pass is replayed on
+ * the host.  Returns the number of matches (>= 0) or a negative error. */
+int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, const uint8_t *d1, int n1,
+                                   const orbx_keypoint *k2, const uint8_t *d2, int n2, float min_x, float max_x,
+                                   float min_y, float max_y, float *prev_matched, int window_size, float nnratio,
+                                   int check_orientation, int *matches12, int64_t *pair_count);
+
+/* ---------------------------------------------------------------- synthetic input */
+
+/* Deterministic test/benchmark image (splitmix64 stream seeded with `seed`): gray 128 canvas,
+ * width*height/300 filled rectangles (variant 0: gray 0..255; variant 2: gray 118..138, low
+ * contrast) and uniform noise in [-3,3].  variant 1: canvas and noise only. Host function. */
+int orbx_synth_image(uint64_t seed, int width, int height, int variant, uint8_t *dst, int stride_bytes);
+/* Deterministic random descriptors (n rows of 32 bytes). Host function. */
+int orbx_synth_descriptors(uint64_t seed, int64_t n, uint8_t *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

@@ -1,0 +1,243 @@
+"""ctypes binding of oracle/liborb_oracle.so, the CPU restatement of the reference's ORB front end.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline leg of
+bench.py.  The product package (orbslam2_amd) never imports this module.  Parity unpinned: see the
+header of orb_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborb_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+MAX_LEVELS = 16
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("blur_variant", C.c_int)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("nlevels", C.c_int), ("w", C.c_int * MAX_LEVELS), ("h", C.c_int * MAX_LEVELS),
+                ("img", C.POINTER(C.c_uint8) * MAX_LEVELS), ("blur", C.POINTER(C.c_uint8) * MAX_LEVELS),
+                ("ncand", C.c_int * MAX_LEVELS), ("nkeep", C.c_int * MAX_LEVELS)]
+
+
+_lib = None
+_ip = C.POINTER(C.c_int)
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        h = C.CDLL(LIB_PATH)
+        h.orc_fast_atan2.restype = C.c_float
+        h.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        h.orc_ic_angle.restype = C.c_float
+        h.orc_ic_angle.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip]
+        h.orc_brief_descriptor.restype = None
+        h.orc_brief_descriptor.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp]
+        h.orc_extract.argtypes = [C.POINTER(Params), _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, _ip,
+                                  C.POINTER(Trace)]
+        h.orc_trace_free.argtypes = [C.POINTER(Trace)]
+        h.orc_trace_free.restype = None
+        h.orc_match_top2.restype = None
+        h.orc_match_top2.argtypes = [_vp, C.c_int, _vp, C.c_int64, C.c_int64, _vp, _vp, _vp]
+        h.orc_search_for_initialization.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_float, C.c_float,
+                                                    C.c_float, C.c_float, _vp, C.c_int, C.c_float, C.c_int, _vp,
+                                                    C.POINTER(C.c_int64)]
+        h.orc_scale_tables.restype = None
+        h.orc_scale_tables.argtypes = [C.c_float, C.c_int, _fp, _fp, _fp, _fp]
+        h.orc_features_per_level.restype = None
+        h.orc_features_per_level.argtypes = [C.c_int, C.c_float, C.c_int, _ip]
+        h.orc_umax.restype = None
+        h.orc_umax.argtypes = [_ip]
+        h.orc_resize_linear_u8.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int]
+        h.orc_gauss7_u8.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int]
+        h.orc_fast_arc_score.argtypes = [_vp, C.c_int]
+        h.orc_fast_detect.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, C.c_int]
+        h.orc_level_candidates.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, C.c_int]
+        h.orc_distribute_octree.argtypes = [_ip, _ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip,
+                                            C.c_int]
+        h.orc_descriptor_distance.argtypes = [_vp, _vp]
+        h.orc_ratio_accept.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float]
+        h.orc_three_maxima.restype = None
+        h.orc_three_maxima.argtypes = [_ip, C.c_int, _ip, _ip, _ip]
+        _lib = h
+    return _lib
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def scale_tables(scale_factor, nlevels):
+    t = [np.zeros(nlevels, np.float32) for _ in range(4)]
+    lib().orc_scale_tables(scale_factor, nlevels, *[a.ctypes.data_as(_fp) for a in t])
+    return t
+
+
+def features_per_level(nfeatures, scale_factor, nlevels):
+    q = np.zeros(nlevels, np.int32)
+    lib().orc_features_per_level(nfeatures, scale_factor, nlevels, _i(q))
+    return q
+
+
+def umax():
+    u = np.zeros(17, np.int32)
+    lib().orc_umax(_i(u))
+    return u[:16]
+
+
+def resize(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    rc = lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+    assert rc == 0
+    return dst
+
+
+def gauss7(src, variant=0):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    rc = lib().orc_gauss7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0], variant)
+    assert rc == 0
+    return dst
+
+
+def fast_arc_score(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_fast_arc_score(C.c_void_p(img.ctypes.data + y * img.strides[0] + x), img.strides[0])
+
+
+def fast_detect(win, threshold, nonmax=True):
+    win = np.ascontiguousarray(win, np.uint8)
+    h, w = win.shape
+    cap = w * h
+    xs, ys, rs = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().orc_fast_detect(_p(win), w, h, win.strides[0], threshold, int(nonmax), _i(xs), _i(ys), _i(rs), cap)
+    return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
+
+
+def level_candidates(img, ini_th, min_th):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    cap = w * h // 4 + 16
+    xs, ys, rs = (np.zeros(cap, np.int32) for _ in range(3))
+    n = lib().orc_level_candidates(_p(img), w, h, img.strides[0], ini_th, min_th, _i(xs), _i(ys), _i(rs), cap)
+    assert n <= cap
+    return xs[:n].copy(), ys[:n].copy(), rs[:n].copy()
+
+
+def distribute_octree(xs, ys, resp, min_x, max_x, min_y, max_y, quota):
+    xs = np.ascontiguousarray(xs, np.int32)
+    ys = np.ascontiguousarray(ys, np.int32)
+    resp = np.ascontiguousarray(resp, np.int32)
+    cap = len(xs) + 8
+    out = np.zeros(cap, np.int32)
+    n = lib().orc_distribute_octree(_i(xs), _i(ys), _i(resp), len(xs), min_x, max_x, min_y, max_y, quota, _i(out),
+                                    cap)
+    if n < 0:
+        raise ValueError("orc_distribute_octree: %d" % n)
+    return out[:n].copy()
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(y, x)
+
+
+def ic_angle(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    u = np.zeros(17, np.int32)
+    lib().orc_umax(_i(u))
+    m10, m01 = C.c_int(0), C.c_int(0)
+    a = lib().orc_ic_angle(_p(img), img.strides[0], x, y, _i(u), C.byref(m10), C.byref(m01))
+    return a, m10.value, m01.value
+
+
+def brief_descriptor(blurred, x, y, angle_deg):
+    blurred = np.ascontiguousarray(blurred, np.uint8)
+    d = np.zeros(32, np.uint8)
+    lib().orc_brief_descriptor(_p(blurred), blurred.strides[0], x, y, angle_deg, _p(d))
+    return d
+
+
+def extract(image, nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant=0, trace=False):
+    """Returns (keypoints, descriptors[, trace dict]).  Empty image -> (None, None)."""
+    if image is None or image.size == 0:
+        return (None, None, None) if trace else (None, None)
+    image = np.ascontiguousarray(image, np.uint8)
+    h, w = image.shape
+    p = Params(nfeatures, scale_factor, nlevels, ini_th, min_th, blur_variant)
+    cap = nfeatures + 4 * nlevels + 64
+    while True:
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = C.c_int(0)
+        tr = Trace()
+        rc = lib().orc_extract(C.byref(p), _p(image), w, h, image.strides[0], _p(kps), _p(desc), cap, C.byref(n),
+                               C.byref(tr) if trace else None)
+        if rc != 0:
+            raise ValueError("orc_extract: %d" % rc)
+        if n.value <= cap:
+            break
+        if trace:
+            lib().orc_trace_free(C.byref(tr))
+        cap = n.value
+    if not trace:
+        return kps[:n.value].copy(), desc[:n.value].copy()
+    info = {"levels": [], "blur": [], "ncand": list(tr.ncand[:nlevels]), "nkeep": list(tr.nkeep[:nlevels])}
+    for l in range(nlevels):
+        lw, lh = tr.w[l], tr.h[l]
+        info["levels"].append(np.ctypeslib.as_array(tr.img[l], shape=(lh, lw)).copy())
+        info["blur"].append(np.ctypeslib.as_array(tr.blur[l], shape=(lh, lw)).copy() if tr.blur[l] else None)
+    lib().orc_trace_free(C.byref(tr))
+    return kps[:n.value].copy(), desc[:n.value].copy(), info
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a), _p(b))
+
+
+def match_top2(q, db, idx_base=0):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    db = np.ascontiguousarray(db, np.uint8).reshape(-1, 32)
+    nq = q.shape[0]
+    best = np.zeros(nq, np.int32)
+    d1 = np.zeros(nq, np.uint16)
+    d2 = np.zeros(nq, np.uint16)
+    lib().orc_match_top2(_p(q), nq, _p(db), db.shape[0], idx_base, _p(best), _p(d1), _p(d2))
+    return best, d1, d2
+
+
+def search_for_initialization(k1, d1, k2, d2, bounds, prev_matched, window, nnratio, check_ori):
+    k1 = np.ascontiguousarray(k1, KEYPOINT_DTYPE)
+    k2 = np.ascontiguousarray(k2, KEYPOINT_DTYPE)
+    d1 = np.ascontiguousarray(d1, np.uint8)
+    d2 = np.ascontiguousarray(d2, np.uint8)
+    m12 = np.full(len(k1), -1, np.int32)
+    pairs = C.c_int64(0)
+    n = lib().orc_search_for_initialization(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), bounds[0], bounds[1],
+                                            bounds[2], bounds[3], _p(prev_matched), window, nnratio, int(check_ori),
+                                            _p(m12), C.byref(pairs))
+    return n, m12, pairs.value

@@ -1,0 +1,108 @@
+"""ctypes binding of liborbx.so (the C ABI declared in include/orbx.h).
+
+The library is the product: there is no fallback.  If it is missing, or a call needs a GPU
+and none is usable, the call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborbx.so")
+
+OK, E_ARG, E_HIP, E_CAPACITY, E_GEOMETRY, E_NODEVICE, E_STATE = 0, -1, -2, -3, -4, -5, -6
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().orbx_strerror(code).decode()
+        if code == E_HIP:
+            msg += " (hipError %d)" % lib().orbx_last_hip_error()
+        super().__init__("%s: %s [%d]" % (where, msg, code))
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("blur_variant", C.c_int),
+                ("max_width", C.c_int), ("max_height", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+
+
+# numpy view of orbx_keypoint / cv::KeyPoint (28 bytes)
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+_P = C.c_void_p
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int)
+_f32p = C.POINTER(C.c_float)
+_u16p = C.POINTER(C.c_uint16)
+
+# name -> (restype, argtypes); every symbol declared in include/orbx.h plus the debug entries
+SIGNATURES = {
+    "orbx_strerror": (C.c_char_p, [C.c_int]),
+    "orbx_last_hip_error": (C.c_int, []),
+    "orbx_version": (C.c_int, []),
+    "orbx_extractor_create": (C.c_int, [C.POINTER(Params), C.POINTER(_P)]),
+    "orbx_extractor_destroy": (None, [_P]),
+    "orbx_extractor_set_stream": (C.c_int, [_P, _P]),
+    "orbx_extractor_levels": (C.c_int, [_P]),
+    "orbx_extractor_scale_tables": (C.c_int, [_P, _f32p, _f32p, _f32p, _f32p]),
+    "orbx_extractor_features_per_level": (C.c_int, [_P, _i32p]),
+    "orbx_extractor_max_keypoints": (C.c_int, [_P]),
+    "orbx_extract": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _i32p]),
+    "orbx_extract_batch_device": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64]),
+    "orbx_extract_batch_host": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "orbx_batch_counts": (C.c_int, [_P, _i32p, _i32p]),
+    "orbx_batch_download": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _i32p]),
+    "orbx_batch_device_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _i32p]),
+    "orbx_pyramid_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _i32p, _i32p]),
+    "orbx_debug_level_map": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "orbx_debug_candidates": (C.c_int, [_P, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int, _i32p]),
+    "orbx_debug_octree": (C.c_int, [C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p,
+                                    C.c_int, _i32p]),
+    "orbx_descriptor_distance": (C.c_int, [_P, _P]),
+    "orbx_matcher_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(_P)]),
+    "orbx_matcher_destroy": (None, [_P]),
+    "orbx_matcher_set_stream": (C.c_int, [_P, _P]),
+    "orbx_match_top2_device": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P, _P, _P]),
+    "orbx_match_top2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P, _P, _P]),
+    "orbx_top2_merge": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "orbx_ratio_test": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_float, _P]),
+    "orbx_search_for_initialization": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float,
+                                                 C.c_float, C.c_float, _P, C.c_int, C.c_float, C.c_int, _P,
+                                                 C.POINTER(C.c_int64)]),
+    "orbx_synth_image": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
+    "orbx_synth_descriptors": (C.c_int, [C.c_uint64, C.c_int64, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads liborbx.so once; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("liborbx.so not found at %s: build it with `make -C orbslam2_amd/csrc` "
+                               "(or __graft_entry__.build())" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, where):
+    if code < 0:
+        raise OrbxError(code, where)
+    return code
+
+
+def ptr(a):
+    """Data pointer of a C-contiguous numpy array as a void pointer."""
+    return C.c_void_p(a.ctypes.data)

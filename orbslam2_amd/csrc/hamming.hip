@@ -1,0 +1,126 @@
+// 256-bit Hamming matching: brute-force top-2 per query over a descriptor database, and distances
+// of an explicit pair list.  ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1744-1760 of the
+// reference) is a popcount of a XOR; the top-2 bookkeeping is the inner loop of SearchByBoW
+// (src/ORBmatcher.cc:217-242): best and second start at 256, strict '<', first index wins.
+#include "orbx_internal.h"
+
+// A (distance, row) pair packed as distance<<16 | row-in-chunk orders exactly like the reference's
+// updates: a smaller distance wins, and among equal distances the earlier row.
+#define TOP2_INIT ((256u << 16) | 0xffffu)
+
+// Each lane owns one query (8 dwords in registers); the database rows of the chunk are the same for
+// every lane, so they arrive through scalar loads and feed v_xor / v_bcnt (which accumulates) directly:
+// 16 vector instructions per pair plus 3 for the packed top-2 update.
+__global__ __launch_bounds__(256) void k_top2_partial(const uint32_t *__restrict__ q, int nq,
+                                                      const uint32_t *__restrict__ db, long long ndb, int chunk_rows,
+                                                      uint2 *__restrict__ partial)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    uint32_t a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        a[i] = qi < nq ? q[(size_t)qi * 8 + i] : 0u;
+    const long long row0 = (long long)blockIdx.y * chunk_rows;
+    const int rows = (int)min((long long)chunk_rows, ndb - row0);
+    const uint32_t *base = db + (size_t)row0 * 8;
+    uint32_t k1 = TOP2_INIT, k2 = TOP2_INIT;
+    int j = 0;
+    for (; j + 4 <= rows; j += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t *r = base + (size_t)(j + u) * 8;
+            uint32_t d = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                d += __popc(a[i] ^ r[i]);
+            const uint32_t key = (d << 16) | (uint32_t)(j + u);
+            const uint32_t lo = min(k1, key);
+            k2 = min(k2, max(k1, key));
+            k1 = lo;
+        }
+    }
+    for (; j < rows; j++) {
+        const uint32_t *r = base + (size_t)j * 8;
+        uint32_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            d += __popc(a[i] ^ r[i]);
+        const uint32_t key = (d << 16) | (uint32_t)j;
+        const uint32_t lo = min(k1, key);
+        k2 = min(k2, max(k1, key));
+        k1 = lo;
+    }
+    if (qi < nq)
+        partial[(size_t)blockIdx.y * nq + qi] = make_uint2(k1, k2);
+}
+
+// one thread per query: fold the chunks in ascending row order
+__global__ __launch_bounds__(256) void k_top2_merge(const uint2 *__restrict__ partial, int nq, int nchunks,
+                                                    int chunk_rows, long long idx_base, int32_t *__restrict__ best,
+                                                    uint16_t *__restrict__ d1, uint16_t *__restrict__ d2)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq)
+        return;
+    int b1 = 256, b2 = 256;
+    long long bi = -1;
+    for (int c = 0; c < nchunks; c++) {
+        const uint2 p = partial[(size_t)c * nq + qi];
+        const int da = p.x >> 16, db = p.y >> 16;
+        if (da < b1) {
+            b2 = b1;
+            b1 = da;
+            bi = (long long)c * chunk_rows + (p.x & 0xffff);
+        } else if (da < b2)
+            b2 = da;
+        if (db < b2)
+            b2 = db;
+    }
+    best[qi] = bi < 0 ? -1 : (int32_t)(bi + idx_base);
+    d1[qi] = (uint16_t)b1;
+    d2[qi] = (uint16_t)b2;
+}
+
+hipError_t orbx_launch_top2(const uint8_t *d_q, int nq, const uint8_t *d_db, int64_t ndb, int64_t idx_base,
+                            uint32_t *d_partial, int chunk_rows, int nchunks, int32_t *d_best, uint16_t *d_d1,
+                            uint16_t *d_d2, hipStream_t s)
+{
+    const int qblocks = (nq + 255) / 256;
+    if (nchunks > 0) {
+        k_top2_partial<<<dim3(qblocks, nchunks), 256, 0, s>>>(reinterpret_cast<const uint32_t *>(d_q), nq,
+                                                              reinterpret_cast<const uint32_t *>(d_db), (long long)ndb,
+                                                              chunk_rows, reinterpret_cast<uint2 *>(d_partial));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    k_top2_merge<<<qblocks, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_partial), nq, nchunks, chunk_rows,
+                                         (long long)idx_base, d_best, d_d1, d_d2);
+    return hipGetLastError();
+}
+
+// distances of an explicit (row of A, row of B) pair list
+__global__ __launch_bounds__(256) void k_pair_dist(const uint4 *__restrict__ da, const uint4 *__restrict__ dbs,
+                                                   const int2 *__restrict__ pairs, int n, uint16_t *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    const int2 p = pairs[i];
+    const uint4 a0 = da[(size_t)p.x * 2], a1 = da[(size_t)p.x * 2 + 1];
+    const uint4 b0 = dbs[(size_t)p.y * 2], b1 = dbs[(size_t)p.y * 2 + 1];
+    const int d = __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                  __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+    out[i] = (uint16_t)d;
+}
+
+hipError_t orbx_launch_pair_dist(const uint8_t *d_a, const uint8_t *d_b, const int *d_pairs, int n, uint16_t *d_out,
+                                 hipStream_t s)
+{
+    if (n <= 0)
+        return hipSuccess;
+    k_pair_dist<<<(n + 255) / 256, 256, 0, s>>>(reinterpret_cast<const uint4 *>(d_a),
+                                                reinterpret_cast<const uint4 *>(d_b),
+                                                reinterpret_cast<const int2 *>(d_pairs), n, d_out);
+    return hipGetLastError();
+}

@@ -1,0 +1,388 @@
+// Quadtree distribution of the FAST candidates of one pyramid level
+// (ORBextractor::DistributeOctTree + ExtractorNode::DivideNode, src/ORBextractor.cc:518-813 of the
+// reference), replayed exactly but without its linked list:
+//
+// The reference keeps the nodes in a std::list.  A round replaces every processed node by its
+// non-empty children, pushed to the FRONT in the order n1..n4, and erases the parent.  So after a
+// round the list is:  children of the last processed node (n4,n3,n2,n1), ..., children of the first
+// processed node, then every unprocessed node in its old order.  That is a pure function of the
+// processing order and of the child key counts, so one workgroup computes each round with prefix
+// sums over an array that holds the node records in list order:
+//   round of the first kind  (:652-711): every node with >1 key is processed, in list order;
+//   round of the last kind   (:726-787): the nodes with >1 key are processed in descending
+//       (key count, creation order) and the round stops as soon as the list has N nodes.
+// The reference sorts on (count, heap address of the node); creation order stands in for the
+// address (a node created later counts as larger).  All nodes with >1 key were created in the
+// preceding round, so the creation index inside that round is enough.
+// Afterwards each node keeps its best-response key, the first such key in candidate order (:791-810).
+#include "orbx_internal.h"
+
+struct OctLevel {
+    int cand_base, quota, n_ini, node_cap, kp_base, region_h;
+    float hx;
+};
+struct OctArgs {
+    int nlevels, cand_per_frame, kp_per_frame;
+    OctLevel lv[ORBX_MAX_LEVELS];
+};
+
+// arrays of `cap` ints carved from dynamic LDS
+struct OctLds {
+    int *bx[2], *by[2], *cnt[2], *seq[2];  // node records in list order, double buffered
+    int *cc[4];                            // child key counts of the node at a list position
+    int *prank;                            // processing rank of an expandable node, -1 otherwise
+    int *order;                            // order[r] = list position of the r-th processed node
+    int *nzs;                              // inclusive prefix over r of the non-empty child counts
+    int *spos;                             // new position of a surviving node
+};
+#define OCT_ARRAYS 16
+#define OCT_TAIL_INTS 8  // wave sums of the block scan + the root count, behind the arrays
+
+size_t orbx_octree_lds_bytes(int node_cap) { return ((size_t)OCT_ARRAYS * node_cap + OCT_TAIL_INTS) * sizeof(int); }
+
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if ((int)(threadIdx.x & 63) >= d)
+            v += t;
+    }
+    return v;
+}
+
+// exclusive prefix of one value per thread over the 256-thread block; *total = block sum
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum /* 4 ints of LDS */, int *total)
+{
+    const int inc = wave_incl_scan(v);
+    const int wv = threadIdx.x >> 6;
+    __syncthreads();  // wsum may still be read from a previous call
+    if ((threadIdx.x & 63) == 63)
+        wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; i++)
+        base += wsum[i];
+    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return base + inc - v;
+}
+
+__device__ __forceinline__ int quadrant_of(uint32_t xy, int bx, int by)
+{
+    const int x = xy & 0xffff, y = xy >> 16;
+    const int ulx = bx & 0xffff, urx = bx >> 16, uly = by & 0xffff, bry = by >> 16;
+    const int midx = ulx + ((urx - ulx + 1) >> 1);  // UL.x + ceil((UR.x-UL.x)/2)
+    const int midy = uly + ((bry - uly + 1) >> 1);
+    return (x < midx ? 0 : 1) + (y < midy ? 0 : 2);  // n1, n2, n3, n4 -> 0..3
+}
+
+// Body shared by the batched kernel and the standalone test entry.
+// xy/resp/node: the n candidates of this level (coordinates relative to the detection region's corner).
+// out_*: kept keypoints in list order (xy as given, plus `add` on both coordinates); out_idx optional.
+__device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__restrict__ resp,
+                            uint16_t *__restrict__ node, int n, int quota, int n_ini, float hx, int region_h,
+                            int cap, int add, uint32_t *__restrict__ out_xy, uint8_t *__restrict__ out_resp,
+                            int *__restrict__ out_idx, int *__restrict__ out_n, int *__restrict__ status)
+{
+    // all LDS lives in the one dynamic array, so its base alignment is not disturbed
+    extern __shared__ __attribute__((aligned(16))) int lds[];
+    int *wsum = lds + (size_t)OCT_ARRAYS * cap;
+    int &sh_size = wsum[4];
+    OctLds L;
+    {
+        int *p = lds;
+        for (int b = 0; b < 2; b++) {
+            L.bx[b] = p, p += cap;
+            L.by[b] = p, p += cap;
+            L.cnt[b] = p, p += cap;
+            L.seq[b] = p, p += cap;
+        }
+        for (int q = 0; q < 4; q++)
+            L.cc[q] = p, p += cap;
+        L.prank = p, p += cap;
+        L.order = p, p += cap;
+        L.nzs = p, p += cap;
+        L.spos = p, p += cap;
+    }
+    const int tid = threadIdx.x;
+    if (n <= 0) {
+        if (tid == 0)
+            *out_n = 0;
+        return;
+    }
+    const int N = quota;
+
+    // ---- roots (:587-631) ----
+    for (int i = tid; i < n_ini; i += 256) {
+        const int ulx = (int)(hx * (float)i), urx = (int)(hx * (float)(i + 1));
+        L.bx[1][i] = ulx | (urx << 16);
+        L.by[1][i] = 0 | (region_h << 16);
+        L.cnt[1][i] = 0;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) {
+        int r = (int)((float)(xy[k] & 0xffff) / hx);
+        r = r < n_ini ? r : n_ini - 1;
+        node[k] = (uint16_t)r;
+        atomicAdd(&L.cnt[1][r], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        for (int i = 0; i < n_ini; i++) {
+            if (L.cnt[1][i] > 0) {
+                L.bx[0][s] = L.bx[1][i], L.by[0][s] = L.by[1][i], L.cnt[0][s] = L.cnt[1][i], L.seq[0][s] = s;
+                L.spos[i] = s++;
+            } else
+                L.spos[i] = 0;
+        }
+        sh_size = s;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += 256)
+        node[k] = (uint16_t)L.spos[node[k]];
+    int size = sh_size;
+    int cur = 0;
+    bool last_kind = false;
+    __syncthreads();
+
+    for (int round = 0; round < 64; round++) {
+        const int prev_size = size;
+        int *bx = L.bx[cur], *by = L.by[cur], *cnt = L.cnt[cur], *seq = L.seq[cur];
+        int *nbx = L.bx[cur ^ 1], *nby = L.by[cur ^ 1], *ncnt = L.cnt[cur ^ 1], *nseq = L.seq[cur ^ 1];
+        const int per = (size + 255) / 256;
+        const int lo = min(tid * per, size), hi = min(lo + per, size);
+
+        // ---- processing order of the nodes that hold more than one key ----
+        int my_e = 0;
+        for (int i = lo; i < hi; i++) {
+            my_e += cnt[i] >= 2;
+            L.cc[0][i] = L.cc[1][i] = L.cc[2][i] = L.cc[3][i] = 0;
+        }
+        int m;
+        int ebase = block_excl_scan(my_e, wsum, &m);
+        if (!last_kind) {
+            for (int i = lo; i < hi; i++)
+                L.prank[i] = cnt[i] >= 2 ? ebase++ : -1;
+        } else {
+            for (int i = lo; i < hi; i++) {
+                int rk = -1;
+                if (cnt[i] >= 2) {
+                    rk = 0;
+                    const int ci = cnt[i], si = seq[i];
+                    for (int j = 0; j < size; j++) {
+                        const int cj = cnt[j];
+                        rk += (cj >= 2) && (cj > ci || (cj == ci && seq[j] > si));
+                    }
+                }
+                L.prank[i] = rk;
+            }
+        }
+        __syncthreads();
+        for (int i = lo; i < hi; i++)
+            if (L.prank[i] >= 0)
+                L.order[L.prank[i]] = i;
+
+        // ---- key counts of the four children (:551-565) ----
+        for (int k = tid; k < n; k += 256) {
+            const int i = node[k];
+            if (cnt[i] >= 2)
+                atomicAdd(&L.cc[quadrant_of(xy[k], bx[i], by[i])][i], 1);
+        }
+        __syncthreads();
+
+        // ---- how many nodes are processed: all, or up to the one that brings the list to N ----
+        const int rper = (m + 255) / 256;
+        const int rlo = min(tid * rper, m), rhi = min(rlo + rper, m);
+        int my_nz = 0;
+        for (int r = rlo; r < rhi; r++) {
+            const int i = L.order[r];
+            my_nz += (L.cc[0][i] > 0) + (L.cc[1][i] > 0) + (L.cc[2][i] > 0) + (L.cc[3][i] > 0);
+        }
+        int nz_total;
+        int run = block_excl_scan(my_nz, wsum, &nz_total);
+        int below = 0;  // processed nodes after which the list is still shorter than N
+        for (int r = rlo; r < rhi; r++) {
+            const int i = L.order[r];
+            run += (L.cc[0][i] > 0) + (L.cc[1][i] > 0) + (L.cc[2][i] > 0) + (L.cc[3][i] > 0);
+            L.nzs[r] = run;  // inclusive; list size after r+1 nodes = size + nzs[r] - (r+1)
+            below += (size + run - (r + 1)) < N;
+        }
+        int t = m;
+        if (last_kind) {
+            int t0;
+            block_excl_scan(below, wsum, &t0);
+            t = min(t0 + 1, m);
+        }
+        __syncthreads();
+        const int children = t > 0 ? L.nzs[t - 1] : 0;
+
+        // ---- survivors keep their relative order behind the new children ----
+        int my_s = 0;
+        for (int i = lo; i < hi; i++)
+            my_s += !(L.prank[i] >= 0 && L.prank[i] < t);
+        int nsurv;
+        int sbase = block_excl_scan(my_s, wsum, &nsurv);
+        const int new_size = children + nsurv;
+        if (new_size > cap) {
+            // cannot happen for a correctly sized list; reported instead of writing out of bounds
+            if (tid == 0) {
+                atomicMax(&status[ORBX_ST_NODE_OVERFLOW], new_size);
+                *out_n = 0;
+            }
+            return;
+        }
+        for (int i = lo; i < hi; i++) {
+            if (!(L.prank[i] >= 0 && L.prank[i] < t)) {
+                const int p = children + sbase++;
+                L.spos[i] = p;
+                nbx[p] = bx[i], nby[p] = by[i], ncnt[p] = cnt[i], nseq[p] = seq[i];
+            }
+        }
+        // ---- children records (:526-548): block of node r starts behind the blocks of r+1..t-1 ----
+        for (int r = rlo; r < rhi; r++) {
+            if (r >= t)
+                break;
+            const int i = L.order[r];
+            const int b_x = bx[i], b_y = by[i];
+            const int ulx = b_x & 0xffff, urx = b_x >> 16, uly = b_y & 0xffff, bry = b_y >> 16;
+            const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
+            const int c[4] = {L.cc[0][i], L.cc[1][i], L.cc[2][i], L.cc[3][i]};
+            const int nz = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+            const int blk = children - L.nzs[r];
+            int before = 0;
+            for (int q = 0; q < 4; q++) {
+                if (c[q] == 0)
+                    continue;
+                const int p = blk + (nz - 1 - before);  // pushed to the front one after the other
+                nbx[p] = (q & 1) ? (midx | (urx << 16)) : (ulx | (midx << 16));
+                nby[p] = (q & 2) ? (midy | (bry << 16)) : (uly | (midy << 16));
+                ncnt[p] = c[q];
+                nseq[p] = L.nzs[r] - nz + before;  // creation index inside this round
+                before++;
+            }
+        }
+        __syncthreads();
+        // ---- move the keys to their new node ----
+        for (int k = tid; k < n; k += 256) {
+            const int i = node[k];
+            const int r = L.prank[i];
+            if (r >= 0 && r < t) {
+                const int q = quadrant_of(xy[k], bx[i], by[i]);
+                const int c[4] = {L.cc[0][i], L.cc[1][i], L.cc[2][i], L.cc[3][i]};
+                const int nz = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+                int before = 0;
+                for (int qq = 0; qq < q; qq++)
+                    before += c[qq] > 0;
+                node[k] = (uint16_t)(children - L.nzs[r] + (nz - 1 - before));
+            } else
+                node[k] = (uint16_t)L.spos[i];
+        }
+        __syncthreads();
+        size = new_size;
+        cur ^= 1;
+
+        // ---- what comes next (:716-723, :784-785) ----
+        if (size >= N || size == prev_size)
+            break;
+        if (!last_kind) {
+            int my_x = 0;
+            const int per2 = (size + 255) / 256;
+            const int lo2 = min(tid * per2, size), hi2 = min(lo2 + per2, size);
+            for (int i = lo2; i < hi2; i++)
+                my_x += L.cnt[cur][i] >= 2;
+            int n_expand;
+            block_excl_scan(my_x, wsum, &n_expand);
+            if (size + 3 * n_expand > N)
+                last_kind = true;
+        }
+        __syncthreads();
+    }
+
+    // ---- best key of every node (:791-810): largest response, first in candidate order ----
+    __syncthreads();
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(L.cc[0]);  // cc[0],cc[1] are adjacent
+    for (int i = tid; i < size; i += 256)
+        best[i] = 0ull;
+    __syncthreads();
+    for (int k = tid; k < n; k += 256)
+        atomicMax(&best[node[k]], ((unsigned long long)resp[k] << 32) | (unsigned long long)(0xffffffffu - (uint32_t)k));
+    __syncthreads();
+    for (int i = tid; i < size; i += 256) {
+        const uint32_t k = 0xffffffffu - (uint32_t)(best[i] & 0xffffffffull);
+        const uint32_t v = xy[k];
+        out_xy[i] = ((v & 0xffff) + add) | (((v >> 16) + add) << 16);
+        out_resp[i] = resp[k];
+        if (out_idx)
+            out_idx[i] = (int)k;
+    }
+    if (tid == 0)
+        *out_n = size;
+}
+
+__global__ __launch_bounds__(256) void k_octree(const uint32_t *__restrict__ cand_xy,
+                                                const uint8_t *__restrict__ cand_resp,
+                                                uint16_t *__restrict__ cand_node, const int *__restrict__ ncand,
+                                                uint32_t *__restrict__ kept_xy, uint8_t *__restrict__ kept_resp,
+                                                int *__restrict__ nkept, int *__restrict__ status, OctArgs a)
+{
+    const int lvl = blockIdx.x, f = blockIdx.y;
+    const OctLevel &L = a.lv[lvl];
+    const size_t cb = (size_t)f * a.cand_per_frame + L.cand_base;
+    const size_t kb = (size_t)f * a.kp_per_frame + L.kp_base;
+    octree_body(cand_xy + cb, cand_resp + cb, cand_node + cb, ncand[f * a.nlevels + lvl], L.quota, L.n_ini, L.hx,
+                L.region_h, L.node_cap, ORBX_BORDER, kept_xy + kb, kept_resp + kb, nullptr,
+                nkept + f * a.nlevels + lvl, status);
+}
+
+hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
+{
+    OctArgs a;
+    a.nlevels = g.nlevels, a.cand_per_frame = g.cand_per_frame, a.kp_per_frame = g.kp_per_frame;
+    int cap = 1;
+    for (int l = 0; l < g.nlevels; l++) {
+        const OrbxLevel &L = g.lv[l];
+        a.lv[l].cand_base = L.cand_base, a.lv[l].quota = L.quota, a.lv[l].n_ini = L.n_ini;
+        a.lv[l].node_cap = L.node_cap, a.lv[l].kp_base = L.kp_base, a.lv[l].region_h = L.max_by - ORBX_BORDER;
+        a.lv[l].hx = L.hx;
+        cap = L.node_cap > cap ? L.node_cap : cap;
+    }
+    // every level carves its own node_cap out of an allocation sized for the largest level
+    const size_t lds = orbx_octree_lds_bytes(cap);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    k_octree<<<dim3(g.nlevels, g.batch), 256, orbx_octree_lds_bytes(cap), s>>>(
+        b.cand_xy, b.cand_resp, b.cand_node, b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status, a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_octree_single(const uint32_t *xy, const uint8_t *resp, uint16_t *node, int n,
+                                                       int quota, int n_ini, float hx, int region_h, int cap,
+                                                       uint32_t *out_xy, uint8_t *out_resp, int *out_idx, int *out_n,
+                                                       int *status)
+{
+    octree_body(xy, resp, node, n, quota, n_ini, hx, region_h, cap, 0, out_xy, out_resp, out_idx, out_n, status);
+}
+
+hipError_t orbx_launch_octree_single(const uint32_t *d_xy, const uint8_t *d_resp, uint16_t *d_node, int n, int region_w,
+                                     int region_h, int quota, uint32_t *d_out_xy, uint8_t *d_out_resp, int *d_out_idx,
+                                     int *d_nout, int *d_status, int node_cap, hipStream_t s)
+{
+    const int n_ini = (int)roundf((float)region_w / (float)region_h);
+    const float hx = (float)region_w / (float)n_ini;
+    const size_t lds = orbx_octree_lds_bytes(node_cap);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree_single),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    k_octree_single<<<1, 256, lds, s>>>(d_xy, d_resp, d_node, n, quota, n_ini, hx,
+                                                                    region_h, node_cap, d_out_xy, d_out_resp,
+                                                                    d_out_idx, d_nout, d_status);
+    return hipGetLastError();
+}

@@ -1,0 +1,1148 @@
+// C ABI of liborbx: handles, level geometry, workspace management and the launch sequence.
+// Host code only; the kernels live in the .hip files next to it.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "orbx_internal.h"
+
+static thread_local int g_last_hip = 0;
+
+#define HIP_TRY(expr)                        \
+    do {                                     \
+        hipError_t e__ = (expr);             \
+        if (e__ != hipSuccess) {             \
+            g_last_hip = (int)e__;           \
+            return ORBX_E_HIP;               \
+        }                                    \
+    } while (0)
+
+extern "C" const char *orbx_strerror(int code)
+{
+    switch (code) {
+    case ORBX_OK: return "ok";
+    case ORBX_E_ARG: return "invalid argument";
+    case ORBX_E_HIP: return "HIP runtime error";
+    case ORBX_E_CAPACITY: return "buffer or workspace too small";
+    case ORBX_E_GEOMETRY: return "image too tall for the quadtree (round(width/height) is 0)";
+    case ORBX_E_NODEVICE: return "no usable GPU";
+    case ORBX_E_STATE: return "call order violated";
+    default: return "unknown error";
+    }
+}
+extern "C" int orbx_last_hip_error(void) { return g_last_hip; }
+extern "C" int orbx_version(void) { return 100; }
+
+// ------------------------------------------------------------------ extractor handle
+
+struct orbx_extractor {
+    orbx_params p;
+    int device;
+    hipStream_t own_stream, stream;
+    float sf[ORBX_MAX_LEVELS], inv[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], invsig2[ORBX_MAX_LEVELS];
+    int quota[ORBX_MAX_LEVELS];
+    OrbxGeom cap_geom;  // geometry of max_width x max_height: sizes every buffer
+    OrbxGeom geom;      // geometry of the last batch
+    int geom_w, geom_h; // image size geom was built for (0 = none)
+    bool have_batch;
+    OrbxBuffers buf;
+    OrbxXCoef *d_xtab;
+    OrbxYCoef *d_ytab;
+    int xtab_cap, ytab_cap;
+    std::vector<int> h_counts, h_nkept;
+};
+
+static inline int round_half_even(float v) { return (int)lrintf(v); }
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+static inline short sat_short(int v) { return (short)std::min(32767, std::max(-32768, v)); }
+
+// scale tables as the reference computes them (src/ORBextractor.cc:437-456): cumulative products
+// in double (the member scaleFactor is a double), each stored as float
+static void scale_tables(orbx_extractor *ex)
+{
+    const double s = (double)ex->p.scale_factor;
+    ex->sf[0] = 1.0f;
+    ex->sig2[0] = 1.0f;
+    for (int i = 1; i < ex->p.nlevels; i++) {
+        ex->sf[i] = (float)((double)ex->sf[i - 1] * s);
+        ex->sig2[i] = ex->sf[i] * ex->sf[i];
+    }
+    for (int i = 0; i < ex->p.nlevels; i++) {
+        ex->inv[i] = 1.0f / ex->sf[i];
+        ex->invsig2[i] = 1.0f / ex->sig2[i];
+    }
+    // per-level quotas (src/ORBextractor.cc:460-475)
+    const float factor = (float)(1.0 / s);
+    float desired = (float)ex->p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)ex->p.nlevels));
+    int sum = 0;
+    for (int l = 0; l < ex->p.nlevels - 1; l++) {
+        ex->quota[l] = round_half_even(desired);
+        sum += ex->quota[l];
+        desired *= factor;
+    }
+    ex->quota[ex->p.nlevels - 1] = std::max(ex->p.nfeatures - sum, 0);
+}
+
+// Level sizes (src/ORBextractor.cc:1195-1197), cell grids (:826-840), quadtree roots (:587-589)
+// and the layout of every per-frame array.  Returns ORBX_E_GEOMETRY for levels the reference cannot
+// distribute (nIni == 0).
+static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, OrbxGeom *g)
+{
+    memset(g, 0, sizeof(*g));
+    g->nlevels = ex->p.nlevels;
+    g->batch = batch;
+    g->ini_th = ex->p.ini_th_fast;
+    g->min_th = ex->p.min_th_fast;
+    g->blur_variant = ex->p.blur_variant;
+    long long off = 0;
+    int cells = 0, tiles = 0, cand = 0, kps = 0, xt = 0, yt = 0;
+    for (int l = 0; l < g->nlevels; l++) {
+        OrbxLevel &L = g->lv[l];
+        L.w = round_half_even((float)w * ex->inv[l]);
+        L.h = round_half_even((float)h * ex->inv[l]);
+        if (L.w < 1 || L.h < 1)
+            return ORBX_E_ARG;
+        L.pitch = align_up(L.w, 64);
+        L.off = (int)off;
+        off += (long long)align_up(L.pitch * L.h, 256);
+        if (off > INT_MAX)
+            return ORBX_E_CAPACITY;
+        L.max_bx = L.w - ORBX_BORDER;
+        L.max_by = L.h - ORBX_BORDER;
+        const float width = (float)(L.max_bx - ORBX_BORDER), height = (float)(L.max_by - ORBX_BORDER);
+        L.ncols = L.nrows = L.wcell = L.hcell = 0;
+        if (width > 0 && height > 0) {
+            const int nc = (int)(width / 30.f), nr = (int)(height / 30.f);
+            if (nc > 0 && nr > 0) {
+                L.ncols = nc, L.nrows = nr;
+                L.wcell = (int)ceilf(width / nc);
+                L.hcell = (int)ceilf(height / nr);
+            }
+        }
+        L.cell_base = cells;
+        cells += L.ncols * L.nrows;
+        L.tiles_x = (L.w + ORBX_FT_W - 1) / ORBX_FT_W;
+        L.tiles_y = (L.h + ORBX_FT_H - 1) / ORBX_FT_H;
+        L.tile_base = tiles;
+        tiles += L.tiles_x * L.tiles_y;
+        L.cand_base = cand;
+        // at most one strict local maximum per 2x2 pixels of a cell
+        L.cand_cap = L.ncols > 0 ? align_up((L.w * L.h) / 4 + 4, 4) : 0;
+        cand += L.cand_cap;
+        L.quota = ex->quota[l];
+        L.n_ini = 1;
+        L.hx = 1.f;
+        if (L.ncols > 0) {
+            L.n_ini = (int)roundf(width / height);
+            if (L.n_ini < 1)
+                return ORBX_E_GEOMETRY;
+            L.hx = width / L.n_ini;
+        }
+        L.node_cap = std::max(L.quota, 4 * L.n_ini) + 4;
+        if (orbx_octree_lds_bytes(L.node_cap) > 160 * 1024)
+            return ORBX_E_ARG;  // the node list of one level must fit the LDS of a compute unit
+        L.kp_base = kps;
+        kps += L.node_cap;
+        L.scale = ex->sf[l];
+        L.patch_size = (int)(31 * ex->sf[l]);
+        L.xtab_off = xt;
+        L.ytab_off = yt;
+        xt += L.w;
+        yt += L.h;
+    }
+    g->cells_per_frame = cells;
+    g->tiles_per_frame = tiles;
+    g->cand_per_frame = cand;
+    g->kp_per_frame = kps;
+    g->out_cap = kps;
+    g->slab = (int)off;
+    return ORBX_OK;
+}
+
+// cv::resize INTER_LINEAR coefficient tables (8-bit path: 11-bit fixed point, half-to-even rounding)
+static void build_resize_tables(const OrbxGeom &g, std::vector<OrbxXCoef> &xt, std::vector<OrbxYCoef> &yt)
+{
+    xt.clear();
+    yt.clear();
+    for (int l = 0; l < g.nlevels; l++) {
+        const OrbxLevel &D = g.lv[l];
+        const size_t x0 = xt.size(), y0 = yt.size();
+        xt.resize(x0 + D.w);
+        yt.resize(y0 + D.h);
+        if (l == 0) {
+            for (int i = 0; i < D.w; i++)
+                xt[x0 + i] = OrbxXCoef{i, 2048, 0};
+            for (int i = 0; i < D.h; i++)
+                yt[y0 + i] = OrbxYCoef{i, i, 2048, 0};
+            continue;
+        }
+        const OrbxLevel &S = g.lv[l - 1];
+        const double scale_x = 1. / ((double)D.w / S.w), scale_y = 1. / ((double)D.h / S.h);
+        int xmax = D.w;
+        for (int dx = 0; dx < D.w; dx++) {
+            float fx = (float)((dx + 0.5) * scale_x - 0.5);
+            int sx = (int)floorf(fx);
+            fx -= sx;
+            if (sx < 0)
+                fx = 0, sx = 0;
+            if (sx + 1 >= S.w) {
+                xmax = std::min(xmax, dx);
+                if (sx >= S.w - 1)
+                    fx = 0, sx = S.w - 1;
+            }
+            OrbxXCoef c;
+            c.sx = sx;
+            c.a0 = sat_short(round_half_even((1.f - fx) * 2048));
+            c.a1 = sat_short(round_half_even(fx * 2048));
+            xt[x0 + dx] = c;
+        }
+        for (int dx = xmax; dx < D.w; dx++) {  // columns right of xmax take the source pixel unweighted
+            xt[x0 + dx].a0 = 2048;
+            xt[x0 + dx].a1 = 0;
+        }
+        for (int dy = 0; dy < D.h; dy++) {
+            float fy = (float)((dy + 0.5) * scale_y - 0.5);
+            int sy = (int)floorf(fy);
+            fy -= sy;
+            OrbxYCoef c;
+            c.sy0 = std::min(std::max(sy, 0), S.h - 1);
+            c.sy1 = std::min(std::max(sy + 1, 0), S.h - 1);
+            c.b0 = sat_short(round_half_even((1.f - fy) * 2048));
+            c.b1 = sat_short(round_half_even(fy * 2048));
+            yt[y0 + dy] = c;
+        }
+    }
+}
+
+template <typename T> static hipError_t dmalloc(T **p, size_t n)
+{
+    *p = nullptr;
+    return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+static void free_buffers(orbx_extractor *ex)
+{
+    OrbxBuffers &b = ex->buf;
+    void *ptrs[] = {b.pyr,       b.blur,    b.nms,       b.cell_cnt, b.cell_off, b.ncand,  b.cand_xy, b.cand_resp,
+                    b.cand_node, b.kept_xy, b.kept_resp, b.nkept,    b.out_kp,   b.out_desc, b.out_n,  b.status,
+                    ex->d_xtab,  ex->d_ytab};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    memset(&ex->buf, 0, sizeof(ex->buf));
+    ex->d_xtab = nullptr;
+    ex->d_ytab = nullptr;
+}
+
+extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor **out)
+{
+    if (!params || !out)
+        return ORBX_E_ARG;
+    *out = nullptr;
+    const orbx_params &p = *params;
+    if (p.nfeatures < 1 || p.nlevels < 1 || p.nlevels > ORBX_MAX_LEVELS || !(p.scale_factor > 1.0f) ||
+        p.max_width < 1 || p.max_height < 1 || p.max_width > 32767 || p.max_height > 32767 || p.max_batch < 1 ||
+        p.blur_variant < 0 || p.blur_variant > 1)
+        return ORBX_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p.device < 0 || p.device >= ndev)
+        return ORBX_E_NODEVICE;
+    orbx_extractor *ex = new (std::nothrow) orbx_extractor();
+    if (!ex)
+        return ORBX_E_CAPACITY;
+    ex->p = p;
+    ex->device = p.device;
+    ex->geom_w = ex->geom_h = 0;
+    ex->have_batch = false;
+    ex->own_stream = ex->stream = nullptr;
+    memset(&ex->buf, 0, sizeof(ex->buf));
+    ex->d_xtab = nullptr;
+    ex->d_ytab = nullptr;
+    scale_tables(ex);
+    int rc = build_geometry(ex, p.max_width, p.max_height, p.max_batch, &ex->cap_geom);
+    if (rc == ORBX_E_GEOMETRY) {
+        // the bound image itself may be too tall; size the workspace from a square of the larger side
+        const int side = std::max(p.max_width, p.max_height);
+        rc = build_geometry(ex, side, side, p.max_batch, &ex->cap_geom);
+    }
+    if (rc != ORBX_OK) {
+        delete ex;
+        return rc;
+    }
+    hipError_t e = hipSetDevice(p.device);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&ex->own_stream, hipStreamNonBlocking);
+    ex->stream = ex->own_stream;
+    const OrbxGeom &g = ex->cap_geom;
+    const size_t B = (size_t)p.max_batch;
+    OrbxBuffers &b = ex->buf;
+    if (e == hipSuccess) e = dmalloc(&b.pyr, B * g.slab);
+    if (e == hipSuccess) e = dmalloc(&b.blur, B * g.slab);
+    if (e == hipSuccess) e = dmalloc(&b.nms, B * g.slab);
+    if (e == hipSuccess) e = dmalloc(&b.cell_cnt, B * g.cells_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.cell_off, B * g.cells_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.ncand, B * g.nlevels);
+    if (e == hipSuccess) e = dmalloc(&b.cand_xy, B * g.cand_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.cand_resp, B * g.cand_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.cand_node, B * g.cand_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.kept_xy, B * g.kp_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.kept_resp, B * g.kp_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.nkept, B * g.nlevels);
+    if (e == hipSuccess) e = dmalloc(&b.out_kp, B * g.out_cap);
+    if (e == hipSuccess) e = dmalloc(&b.out_desc, B * g.out_cap * 32);
+    if (e == hipSuccess) e = dmalloc(&b.out_n, B);
+    if (e == hipSuccess) e = dmalloc(&b.status, (size_t)ORBX_ST_COUNT);
+    int xt = 0, yt = 0;
+    for (int l = 0; l < g.nlevels; l++)
+        xt += g.lv[l].w, yt += g.lv[l].h;
+    ex->xtab_cap = xt;
+    ex->ytab_cap = yt;
+    if (e == hipSuccess) e = dmalloc(&ex->d_xtab, (size_t)xt);
+    if (e == hipSuccess) e = dmalloc(&ex->d_ytab, (size_t)yt);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        free_buffers(ex);
+        if (ex->own_stream)
+            (void)hipStreamDestroy(ex->own_stream);
+        delete ex;
+        return ORBX_E_HIP;
+    }
+    b.xtab = ex->d_xtab;
+    b.ytab = ex->d_ytab;
+    *out = ex;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_extractor_destroy(orbx_extractor *ex)
+{
+    if (!ex)
+        return;
+    (void)hipSetDevice(ex->device);
+    (void)hipStreamSynchronize(ex->stream);
+    free_buffers(ex);
+    if (ex->own_stream)
+        (void)hipStreamDestroy(ex->own_stream);
+    delete ex;
+}
+
+extern "C" int orbx_extractor_set_stream(orbx_extractor *ex, void *hip_stream)
+{
+    if (!ex)
+        return ORBX_E_ARG;
+    ex->stream = hip_stream ? (hipStream_t)hip_stream : ex->own_stream;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_levels(const orbx_extractor *ex) { return ex ? ex->p.nlevels : ORBX_E_ARG; }
+
+extern "C" int orbx_extractor_scale_tables(const orbx_extractor *ex, float *scale, float *inv_scale, float *sigma2,
+                                           float *inv_sigma2)
+{
+    if (!ex)
+        return ORBX_E_ARG;
+    for (int i = 0; i < ex->p.nlevels; i++) {
+        if (scale) scale[i] = ex->sf[i];
+        if (inv_scale) inv_scale[i] = ex->inv[i];
+        if (sigma2) sigma2[i] = ex->sig2[i];
+        if (inv_sigma2) inv_sigma2[i] = ex->invsig2[i];
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_features_per_level(const orbx_extractor *ex, int *quota)
+{
+    if (!ex || !quota)
+        return ORBX_E_ARG;
+    for (int i = 0; i < ex->p.nlevels; i++)
+        quota[i] = ex->quota[i];
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_max_keypoints(const orbx_extractor *ex) { return ex ? ex->cap_geom.out_cap : ORBX_E_ARG; }
+
+// geometry of a (w,h) batch; uploads the resize tables when the image size changed
+static int prepare(orbx_extractor *ex, int batch, int w, int h)
+{
+    if (batch < 1 || batch > ex->p.max_batch || w < 1 || h < 1 || w > ex->p.max_width || h > ex->p.max_height)
+        return ORBX_E_CAPACITY;
+    HIP_TRY(hipSetDevice(ex->device));
+    if (w != ex->geom_w || h != ex->geom_h) {
+        OrbxGeom g;
+        int rc = build_geometry(ex, w, h, batch, &g);
+        if (rc != ORBX_OK)
+            return rc;
+        const OrbxGeom &c = ex->cap_geom;
+        if (g.slab > c.slab || g.cells_per_frame > c.cells_per_frame || g.cand_per_frame > c.cand_per_frame ||
+            g.kp_per_frame > c.kp_per_frame)
+            return ORBX_E_CAPACITY;
+        // per-frame strides of the result arrays stay those of the capacity geometry
+        g.kp_per_frame = c.kp_per_frame;
+        g.out_cap = c.out_cap;
+        std::vector<OrbxXCoef> xt;
+        std::vector<OrbxYCoef> yt;
+        build_resize_tables(g, xt, yt);
+        if ((int)xt.size() > ex->xtab_cap || (int)yt.size() > ex->ytab_cap)
+            return ORBX_E_CAPACITY;
+        // the previous batch may still read the old tables
+        HIP_TRY(hipStreamSynchronize(ex->stream));
+        HIP_TRY(hipMemcpy(ex->d_xtab, xt.data(), xt.size() * sizeof(OrbxXCoef), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ex->d_ytab, yt.data(), yt.size() * sizeof(OrbxYCoef), hipMemcpyHostToDevice));
+        ex->geom = g;
+        ex->geom_w = w;
+        ex->geom_h = h;
+    }
+    ex->geom.batch = batch;
+    return ORBX_OK;
+}
+
+// everything after level 0 is in place
+static int run_pipeline(orbx_extractor *ex)
+{
+    const OrbxGeom &g = ex->geom;
+    const OrbxBuffers &b = ex->buf;
+    hipStream_t s = ex->stream;
+    HIP_TRY(hipMemsetAsync(b.status, 0, ORBX_ST_COUNT * sizeof(int), s));
+    for (int l = 1; l < g.nlevels; l++)
+        HIP_TRY(orbx_launch_resize(l, g, b, s));
+    HIP_TRY(orbx_launch_fast_nms(g, b, s));
+    HIP_TRY(orbx_launch_cells(g, b, s));
+    HIP_TRY(orbx_launch_octree(g, b, s));
+    HIP_TRY(orbx_launch_blur(g, b, s));
+    HIP_TRY(orbx_launch_describe(g, b, s));
+    ex->have_batch = true;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int batch, int width, int height,
+                                         int stride_bytes, int64_t frame_stride_bytes)
+{
+    if (!ex || !d_images || stride_bytes < width)
+        return ORBX_E_ARG;
+    int rc = prepare(ex, batch, width, height);
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(orbx_launch_ingest(d_images, stride_bytes, frame_stride_bytes, ex->geom, ex->buf, ex->stream));
+    return run_pipeline(ex);
+}
+
+extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const *images, int batch, int width,
+                                       int height, int stride_bytes)
+{
+    if (!ex || !images || stride_bytes < width)
+        return ORBX_E_ARG;
+    int rc = prepare(ex, batch, width, height);
+    if (rc != ORBX_OK)
+        return rc;
+    const OrbxLevel &L0 = ex->geom.lv[0];
+    for (int f = 0; f < batch; f++) {
+        if (!images[f])
+            return ORBX_E_ARG;
+        HIP_TRY(hipMemcpy2DAsync(ex->buf.pyr + (size_t)f * ex->geom.slab + L0.off, L0.pitch, images[f], stride_bytes,
+                                 width, height, hipMemcpyHostToDevice, ex->stream));
+    }
+    return run_pipeline(ex);
+}
+
+extern "C" int orbx_batch_counts(orbx_extractor *ex, int *n_per_frame, int *n_per_level)
+{
+    if (!ex)
+        return ORBX_E_ARG;
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    HIP_TRY(hipSetDevice(ex->device));
+    const int B = ex->geom.batch, NL = ex->geom.nlevels;
+    ex->h_counts.resize(B);
+    ex->h_nkept.resize((size_t)B * NL);
+    int status[ORBX_ST_COUNT];
+    HIP_TRY(hipMemcpyAsync(ex->h_counts.data(), ex->buf.out_n, sizeof(int) * B, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(ex->h_nkept.data(), ex->buf.nkept, sizeof(int) * B * NL, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(status, ex->buf.status, sizeof(status), hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    if (status[ORBX_ST_CAND_OVERFLOW] || status[ORBX_ST_NODE_OVERFLOW])
+        return ORBX_E_CAPACITY;
+    if (n_per_frame)
+        memcpy(n_per_frame, ex->h_counts.data(), sizeof(int) * B);
+    if (n_per_level)
+        memcpy(n_per_level, ex->h_nkept.data(), sizeof(int) * B * NL);
+    return ORBX_OK;
+}
+
+extern "C" int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *keypoints, uint8_t *descriptors,
+                                   int cap, int *n_out)
+{
+    if (!ex || !n_out)
+        return ORBX_E_ARG;
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    if (frame < 0 || frame >= ex->geom.batch)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(ex->device));
+    int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, ex->buf.out_n + frame, sizeof(int), hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    *n_out = n;
+    if (n > cap)
+        return ORBX_E_CAPACITY;
+    if (n > 0) {
+        const size_t o = (size_t)frame * ex->geom.out_cap;
+        if (keypoints)
+            HIP_TRY(hipMemcpyAsync(keypoints, ex->buf.out_kp + o, sizeof(orbx_keypoint) * n, hipMemcpyDeviceToHost,
+                                   ex->stream));
+        if (descriptors)
+            HIP_TRY(hipMemcpyAsync(descriptors, ex->buf.out_desc + o * 32, (size_t)32 * n, hipMemcpyDeviceToHost,
+                                   ex->stream));
+        HIP_TRY(hipStreamSynchronize(ex->stream));
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_batch_device_results(orbx_extractor *ex, const orbx_keypoint **d_keypoints,
+                                         const uint8_t **d_descriptors, const int32_t **d_counts, int *max_keypoints)
+{
+    if (!ex)
+        return ORBX_E_ARG;
+    if (d_keypoints) *d_keypoints = ex->buf.out_kp;
+    if (d_descriptors) *d_descriptors = ex->buf.out_desc;
+    if (d_counts) *d_counts = ex->buf.out_n;
+    if (max_keypoints) *max_keypoints = ex->cap_geom.out_cap;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height, int stride_bytes,
+                            orbx_keypoint *keypoints, uint8_t *descriptors, int cap, int *n_out)
+{
+    if (!ex || !n_out)
+        return ORBX_E_ARG;
+    if (!image || width <= 0 || height <= 0) {
+        *n_out = -1;  // empty image: the reference returns without touching its outputs
+        return ORBX_OK;
+    }
+    const uint8_t *one[1] = {image};
+    int rc = orbx_extract_batch_host(ex, one, 1, width, height, stride_bytes);
+    if (rc != ORBX_OK)
+        return rc;
+    rc = orbx_batch_counts(ex, nullptr, nullptr);
+    if (rc != ORBX_OK)
+        return rc;
+    return orbx_batch_download(ex, 0, keypoints, descriptors, cap, n_out);
+}
+
+static inline int reflect101(int i, int n)
+{
+    if (n == 1)
+        return 0;
+    while (i < 0 || i >= n)
+        i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+static int download_level(orbx_extractor *ex, const uint8_t *slab_buf, int frame, int level, int border, uint8_t *dst,
+                          int dst_stride, int *width, int *height)
+{
+    if (!ex)
+        return ORBX_E_ARG;
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    if (frame < 0 || frame >= ex->geom.batch || level < 0 || level >= ex->geom.nlevels || border < 0)
+        return ORBX_E_ARG;
+    const OrbxLevel &L = ex->geom.lv[level];
+    if (width) *width = L.w;
+    if (height) *height = L.h;
+    if (!dst)
+        return ORBX_OK;
+    if (dst_stride < L.w + 2 * border)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(ex->device));
+    uint8_t *inner = dst + (size_t)border * dst_stride + border;
+    HIP_TRY(hipMemcpy2DAsync(inner, dst_stride, slab_buf + (size_t)frame * ex->geom.slab + L.off, L.pitch, L.w, L.h,
+                             hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    if (border > 0) {
+        // BORDER_REFLECT_101 frame, as copyMakeBorder leaves it around each level
+        for (int y = 0; y < L.h; y++) {
+            uint8_t *row = inner + (size_t)y * dst_stride;
+            for (int i = 1; i <= border; i++) {
+                row[-i] = row[reflect101(-i, L.w)];
+                row[L.w - 1 + i] = row[reflect101(L.w - 1 + i, L.w)];
+            }
+        }
+        for (int i = 1; i <= border; i++) {
+            memcpy(inner + (ptrdiff_t)(-i) * dst_stride - border,
+                   inner + (ptrdiff_t)reflect101(-i, L.h) * dst_stride - border, L.w + 2 * border);
+            memcpy(inner + (ptrdiff_t)(L.h - 1 + i) * dst_stride - border,
+                   inner + (ptrdiff_t)reflect101(L.h - 1 + i, L.h) * dst_stride - border, L.w + 2 * border);
+        }
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, int border, uint8_t *dst, int dst_stride,
+                                  int *width, int *height)
+{
+    return download_level(ex, ex ? ex->buf.pyr : nullptr, frame, level, border, dst, dst_stride, width, height);
+}
+
+extern "C" int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int level, uint8_t *dst, int dst_stride)
+{
+    if (!ex || !dst || (what != 0 && what != 1))
+        return ORBX_E_ARG;
+    return download_level(ex, what == 0 ? ex->buf.nms : ex->buf.blur, frame, level, 0, dst, dst_stride, nullptr,
+                          nullptr);
+}
+
+extern "C" int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, int *xs, int *ys, int *resp, int cap,
+                                     int *n_out)
+{
+    if (!ex || !n_out)
+        return ORBX_E_ARG;
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    if (frame < 0 || frame >= ex->geom.batch || level < 0 || level >= ex->geom.nlevels)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(ex->device));
+    const OrbxGeom &g = ex->geom;
+    int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, ex->buf.ncand + frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost,
+                           ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    *n_out = n;
+    if (n > cap || n > g.lv[level].cand_cap)
+        return ORBX_E_CAPACITY;
+    if (n == 0)
+        return ORBX_OK;
+    std::vector<uint32_t> xy(n);
+    std::vector<uint8_t> rp(n);
+    const size_t o = (size_t)frame * g.cand_per_frame + g.lv[level].cand_base;
+    HIP_TRY(hipMemcpyAsync(xy.data(), ex->buf.cand_xy + o, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(rp.data(), ex->buf.cand_resp + o, (size_t)n, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    for (int i = 0; i < n; i++) {
+        if (xs) xs[i] = (int)(xy[i] & 0xffff);
+        if (ys) ys[i] = (int)(xy[i] >> 16);
+        if (resp) resp[i] = rp[i];
+    }
+    return ORBX_OK;
+}
+
+// Standalone quadtree run (parity tests): n candidates with coordinates relative to the detection
+// region of region_w x region_h, quota N.  out_idx receives the kept candidate indices in list order.
+extern "C" int orbx_debug_octree(int device, const int *xs, const int *ys, const int *resp, int n, int region_w,
+                                 int region_h, int quota, int *out_idx, int cap, int *n_out)
+{
+    if (!xs || !ys || !resp || !n_out || n < 0 || region_w < 1 || region_h < 1 || quota < 1)
+        return ORBX_E_ARG;
+    const int n_ini = (int)roundf((float)region_w / (float)region_h);
+    if (n_ini < 1)
+        return ORBX_E_GEOMETRY;
+    const int node_cap = std::max(quota, 4 * n_ini) + 4;
+    if (orbx_octree_lds_bytes(node_cap) > 160 * 1024)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(device));
+    std::vector<uint32_t> xy(std::max(n, 1));
+    std::vector<uint8_t> rp(std::max(n, 1));
+    for (int i = 0; i < n; i++) {
+        xy[i] = (uint32_t)xs[i] | ((uint32_t)ys[i] << 16);
+        rp[i] = (uint8_t)resp[i];
+    }
+    uint32_t *d_xy = nullptr, *d_oxy = nullptr;
+    uint8_t *d_rp = nullptr, *d_orp = nullptr;
+    uint16_t *d_node = nullptr;
+    int *d_oidx = nullptr, *d_n = nullptr, *d_st = nullptr;
+    int rc = ORBX_OK;
+    hipError_t e = dmalloc(&d_xy, (size_t)n);
+    if (e == hipSuccess) e = dmalloc(&d_rp, (size_t)n);
+    if (e == hipSuccess) e = dmalloc(&d_node, (size_t)n);
+    if (e == hipSuccess) e = dmalloc(&d_oxy, (size_t)node_cap);
+    if (e == hipSuccess) e = dmalloc(&d_orp, (size_t)node_cap);
+    if (e == hipSuccess) e = dmalloc(&d_oidx, (size_t)node_cap);
+    if (e == hipSuccess) e = dmalloc(&d_n, 1);
+    if (e == hipSuccess) e = dmalloc(&d_st, (size_t)ORBX_ST_COUNT);
+    if (e == hipSuccess) e = hipMemset(d_st, 0, sizeof(int) * ORBX_ST_COUNT);
+    if (e == hipSuccess && n > 0) e = hipMemcpy(d_xy, xy.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n > 0) e = hipMemcpy(d_rp, rp.data(), (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = orbx_launch_octree_single(d_xy, d_rp, d_node, n, region_w, region_h, quota, d_oxy, d_orp, d_oidx, d_n, d_st,
+                                      node_cap, nullptr);
+    int m = 0, st[ORBX_ST_COUNT] = {0};
+    if (e == hipSuccess) e = hipMemcpy(&m, d_n, sizeof(int), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(st, d_st, sizeof(st), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        *n_out = m;
+        if (st[ORBX_ST_NODE_OVERFLOW] || m > cap)
+            rc = ORBX_E_CAPACITY;
+        else if (m > 0 && out_idx)
+            e = hipMemcpy(out_idx, d_oidx, sizeof(int) * m, hipMemcpyDeviceToHost);
+    }
+    void *ptrs[] = {d_xy, d_rp, d_node, d_oxy, d_orp, d_oidx, d_n, d_st};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        return ORBX_E_HIP;
+    }
+    return rc;
+}
+
+// ------------------------------------------------------------------ matcher
+
+extern "C" int orbx_descriptor_distance(const uint8_t *a, const uint8_t *b)
+{
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) +
+           __builtin_popcountll(x[3] ^ y[3]);
+}
+
+struct orbx_matcher {
+    int device;
+    hipStream_t own_stream, stream;
+    int max_queries;
+    uint32_t *d_partial;
+    size_t partial_cap;  // in uint2 entries
+    uint8_t *d_q, *d_db;
+    size_t q_cap, db_cap;  // bytes
+    int32_t *d_best;
+    uint16_t *d_d1, *d_d2;
+    // pair-list scratch
+    uint8_t *d_a, *d_b;
+    int *d_pairs;
+    uint16_t *d_pd;
+    size_t a_cap, b_cap, pairs_cap;
+};
+
+extern "C" int orbx_matcher_create(int device, int max_queries, orbx_matcher **out)
+{
+    if (!out || max_queries < 1)
+        return ORBX_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+        return ORBX_E_NODEVICE;
+    orbx_matcher *m = new (std::nothrow) orbx_matcher();
+    if (!m)
+        return ORBX_E_CAPACITY;
+    memset(m, 0, sizeof(*m));
+    m->device = device;
+    m->max_queries = max_queries;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+    m->stream = m->own_stream;
+    if (e == hipSuccess) e = dmalloc(&m->d_best, (size_t)max_queries);
+    if (e == hipSuccess) e = dmalloc(&m->d_d1, (size_t)max_queries);
+    if (e == hipSuccess) e = dmalloc(&m->d_d2, (size_t)max_queries);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        orbx_matcher_destroy(m);
+        return ORBX_E_HIP;
+    }
+    *out = m;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_matcher_destroy(orbx_matcher *m)
+{
+    if (!m)
+        return;
+    (void)hipSetDevice(m->device);
+    if (m->stream)
+        (void)hipStreamSynchronize(m->stream);
+    void *ptrs[] = {m->d_partial, m->d_q, m->d_db, m->d_best, m->d_d1, m->d_d2, m->d_a, m->d_b, m->d_pairs, m->d_pd};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    if (m->own_stream)
+        (void)hipStreamDestroy(m->own_stream);
+    delete m;
+}
+
+extern "C" int orbx_matcher_set_stream(orbx_matcher *m, void *hip_stream)
+{
+    if (!m)
+        return ORBX_E_ARG;
+    m->stream = hip_stream ? (hipStream_t)hip_stream : m->own_stream;
+    return ORBX_OK;
+}
+
+template <typename T> static int grow(T **p, size_t *cap, size_t need, hipStream_t s)
+{
+    if (need <= *cap)
+        return ORBX_OK;
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*p)
+        HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t n = need + need / 4;
+    HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
+    *cap = n;
+    return ORBX_OK;
+}
+
+// rows per database chunk: enough chunks to fill the chip, row index fits 16 bits
+static void top2_chunks(int nq, int64_t ndb, int *chunk_rows, int *nchunks)
+{
+    const int qblocks = (nq + 255) / 256;
+    const int want = std::max(1, 4096 / qblocks);  // ~4096 workgroups
+    int64_t rows = (ndb + want - 1) / want;
+    rows = std::max<int64_t>(256, std::min<int64_t>(rows, 32768));
+    rows = (rows + 3) / 4 * 4;
+    *chunk_rows = (int)rows;
+    *nchunks = (int)((ndb + rows - 1) / rows);
+}
+
+extern "C" int orbx_match_top2_device(orbx_matcher *m, const uint8_t *d_queries, int nq, const uint8_t *d_db,
+                                      int64_t ndb, int64_t idx_base, int32_t *d_best_idx, uint16_t *d_d1,
+                                      uint16_t *d_d2)
+{
+    if (!m || !d_queries || nq < 1 || ndb < 0 || (ndb > 0 && !d_db) || !d_best_idx || !d_d1 || !d_d2)
+        return ORBX_E_ARG;
+    if (idx_base + ndb > INT32_MAX)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    int chunk_rows = 256, nchunks = 0;
+    if (ndb > 0)
+        top2_chunks(nq, ndb, &chunk_rows, &nchunks);
+    int rc = grow(&m->d_partial, &m->partial_cap, (size_t)std::max(nchunks, 1) * nq * 2, m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(orbx_launch_top2(d_queries, nq, d_db, ndb, idx_base, m->d_partial, chunk_rows, nchunks, d_best_idx, d_d1,
+                             d_d2, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_match_top2(orbx_matcher *m, const uint8_t *queries, int nq, const uint8_t *db, int64_t ndb,
+                               int64_t idx_base, int32_t *best_idx, uint16_t *d1, uint16_t *d2)
+{
+    if (!m || !queries || nq < 1 || nq > m->max_queries || ndb < 0 || (ndb > 0 && !db) || !best_idx || !d1 || !d2)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = grow(&m->d_q, &m->q_cap, (size_t)nq * 32, m->stream);
+    if (rc == ORBX_OK)
+        rc = grow(&m->d_db, &m->db_cap, (size_t)std::max<int64_t>(ndb, 1) * 32, m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(m->d_q, queries, (size_t)nq * 32, hipMemcpyHostToDevice, m->stream));
+    if (ndb > 0)
+        HIP_TRY(hipMemcpyAsync(m->d_db, db, (size_t)ndb * 32, hipMemcpyHostToDevice, m->stream));
+    rc = orbx_match_top2_device(m, m->d_q, nq, m->d_db, ndb, idx_base, m->d_best, m->d_d1, m->d_d2);
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(best_idx, m->d_best, sizeof(int32_t) * nq, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(d1, m->d_d1, sizeof(uint16_t) * nq, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(d2, m->d_d2, sizeof(uint16_t) * nq, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_top2_merge(int nshards, int nq, const int32_t *best_idx, const uint16_t *d1, const uint16_t *d2,
+                               int32_t *out_idx, uint16_t *out_d1, uint16_t *out_d2)
+{
+    if (nshards < 1 || nq < 0 || !best_idx || !d1 || !d2 || !out_idx || !out_d1 || !out_d2)
+        return ORBX_E_ARG;
+    for (int i = 0; i < nq; i++) {
+        int b1 = 256, b2 = 256;
+        int32_t bi = -1;
+        for (int s = 0; s < nshards; s++) {
+            const size_t o = (size_t)s * nq + i;
+            const int a = d1[o], b = d2[o];
+            if (a < b1) {
+                b2 = b1;
+                b1 = a;
+                bi = best_idx[o];
+            } else if (a < b2)
+                b2 = a;
+            if (b < b2)
+                b2 = b;
+        }
+        out_idx[i] = bi;
+        out_d1[i] = (uint16_t)b1;
+        out_d2[i] = (uint16_t)b2;
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_ratio_test(int nq, const uint16_t *d1, const uint16_t *d2, int th, float ratio, uint8_t *accept)
+{
+    if (nq < 0 || !d1 || !d2)
+        return ORBX_E_ARG;
+    int n = 0;
+    for (int i = 0; i < nq; i++) {
+        const int ok = (int)d1[i] <= th && (float)d1[i] < ratio * (float)d2[i];
+        if (accept)
+            accept[i] = (uint8_t)ok;
+        n += ok;
+    }
+    return n;
+}
+
+// ---- SearchForInitialization: candidate windows on the host, distances on the GPU, greedy replay ----
+
+namespace {
+struct FrameGrid {  // Frame::mGrid[64][48] as CSR (src/Frame.cc:239-253, 409-420)
+    static const int COLS = 64, ROWS = 48;
+    float min_x, min_y, inv_w, inv_h;
+    std::vector<int> start, items;
+    void build(const orbx_keypoint *k, int n, float mnx, float mxx, float mny, float mxy)
+    {
+        min_x = mnx, min_y = mny;
+        inv_w = (float)COLS / (mxx - mnx);
+        inv_h = (float)ROWS / (mxy - mny);
+        start.assign(COLS * ROWS + 1, 0);
+        std::vector<int> cell(n);
+        for (int i = 0; i < n; i++) {
+            const int px = (int)roundf((k[i].x - min_x) * inv_w), py = (int)roundf((k[i].y - min_y) * inv_h);
+            cell[i] = (px < 0 || px >= COLS || py < 0 || py >= ROWS) ? -1 : px * ROWS + py;
+            if (cell[i] >= 0)
+                start[cell[i] + 1]++;
+        }
+        for (int c = 0; c < COLS * ROWS; c++)
+            start[c + 1] += start[c];
+        items.resize(n);
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < n; i++)
+            if (cell[i] >= 0)
+                items[fill[cell[i]]++] = i;
+    }
+    // Frame::GetFeaturesInArea (src/Frame.cc:349-407), appending to out
+    void area(const orbx_keypoint *k, float x, float y, float r, int min_level, int max_level,
+              std::vector<int> &out) const
+    {
+        const int x0 = std::max(0, (int)floorf((x - min_x - r) * inv_w));
+        if (x0 >= COLS) return;
+        const int x1 = std::min(COLS - 1, (int)ceilf((x - min_x + r) * inv_w));
+        if (x1 < 0) return;
+        const int y0 = std::max(0, (int)floorf((y - min_y - r) * inv_h));
+        if (y0 >= ROWS) return;
+        const int y1 = std::min(ROWS - 1, (int)ceilf((y - min_y + r) * inv_h));
+        if (y1 < 0) return;
+        const bool check = (min_level > 0) || (max_level >= 0);
+        for (int ix = x0; ix <= x1; ix++)
+            for (int iy = y0; iy <= y1; iy++) {
+                const int c = ix * ROWS + iy;
+                for (int j = start[c]; j < start[c + 1]; j++) {
+                    const orbx_keypoint &kp = k[items[j]];
+                    if (check) {
+                        if (kp.octave < min_level) continue;
+                        if (max_level >= 0 && kp.octave > max_level) continue;
+                    }
+                    if (fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)
+                        out.push_back(items[j]);
+                }
+            }
+    }
+};
+}  // namespace
+
+extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, const uint8_t *d1, int n1,
+                                              const orbx_keypoint *k2, const uint8_t *d2, int n2, float min_x,
+                                              float max_x, float min_y, float max_y, float *prev_matched,
+                                              int window_size, float nnratio, int check_orientation, int *matches12,
+                                              int64_t *pair_count)
+{
+    if (!m || n1 < 0 || n2 < 0 || (n1 > 0 && (!k1 || !d1 || !prev_matched || !matches12)) || (n2 > 0 && (!k2 || !d2)) ||
+        !(max_x > min_x) || !(max_y > min_y))
+        return ORBX_E_ARG;
+    for (int i = 0; i < n1; i++)
+        matches12[i] = -1;
+    if (pair_count)
+        *pair_count = 0;
+    if (n1 == 0 || n2 == 0)
+        return 0;
+    FrameGrid grid;
+    grid.build(k2, n2, min_x, max_x, min_y, max_y);
+    // candidate windows of the level-0 keypoints of frame 1 (:446-455)
+    std::vector<int> first(n1 + 1, 0), cand, pairs;
+    for (int i1 = 0; i1 < n1; i1++) {
+        first[i1] = (int)cand.size();
+        if (k1[i1].octave > 0)
+            continue;
+        grid.area(k2, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, k1[i1].octave, k1[i1].octave,
+                  cand);
+    }
+    first[n1] = (int)cand.size();
+    const int np = (int)cand.size();
+    if (pair_count)
+        *pair_count = np;
+    std::vector<uint16_t> dist(std::max(np, 1));
+    if (np > 0) {
+        pairs.resize((size_t)np * 2);
+        for (int i1 = 0; i1 < n1; i1++)
+            for (int c = first[i1]; c < first[i1 + 1]; c++) {
+                pairs[2 * (size_t)c] = i1;
+                pairs[2 * (size_t)c + 1] = cand[c];
+            }
+        HIP_TRY(hipSetDevice(m->device));
+        int rc = grow(&m->d_a, &m->a_cap, (size_t)n1 * 32, m->stream);
+        if (rc == ORBX_OK) rc = grow(&m->d_b, &m->b_cap, (size_t)n2 * 32, m->stream);
+        if (rc == ORBX_OK) {
+            // pairs (2 ints each) and their distances share one growth step
+            const size_t before = m->pairs_cap;
+            rc = grow(&m->d_pairs, &m->pairs_cap, (size_t)np * 2, m->stream);
+            if (rc == ORBX_OK && m->pairs_cap != before) {
+                if (m->d_pd)
+                    HIP_TRY(hipFree(m->d_pd));
+                m->d_pd = nullptr;
+                HIP_TRY(hipMalloc((void **)&m->d_pd, m->pairs_cap / 2 * sizeof(uint16_t) + 16));
+            }
+        }
+        if (rc != ORBX_OK)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(m->d_a, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(m->d_b, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(m->d_pairs, pairs.data(), sizeof(int) * 2 * (size_t)np, hipMemcpyHostToDevice,
+                               m->stream));
+        HIP_TRY(orbx_launch_pair_dist(m->d_a, m->d_b, m->d_pairs, np, m->d_pd, m->stream));
+        HIP_TRY(hipMemcpyAsync(dist.data(), m->d_pd, sizeof(uint16_t) * (size_t)np, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    // order-dependent part (:459-516): sequential over frame-1 keypoints
+    int nmatches = 0;
+    std::vector<int> matched_dist(n2, INT_MAX), matches21(n2, -1);
+    std::vector<int> hist_item, hist_bin;
+    const float factor = ORBX_HISTO_LENGTH / 360.0f;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (first[i1] == first[i1 + 1])
+            continue;
+        int best = INT_MAX, best2 = INT_MAX, best_idx = -1;
+        for (int c = first[i1]; c < first[i1 + 1]; c++) {
+            const int i2 = cand[c], d = dist[c];
+            if (matched_dist[i2] <= d)
+                continue;
+            if (d < best) {
+                best2 = best;
+                best = d;
+                best_idx = i2;
+            } else if (d < best2)
+                best2 = d;
+        }
+        if (best <= ORBX_TH_LOW && (float)best < (float)best2 * nnratio) {
+            if (matches21[best_idx] >= 0) {
+                matches12[matches21[best_idx]] = -1;
+                nmatches--;
+            }
+            matches12[i1] = best_idx;
+            matches21[best_idx] = i1;
+            matched_dist[best_idx] = best;
+            nmatches++;
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[best_idx].angle;
+                if (rot < 0.0)
+                    rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == ORBX_HISTO_LENGTH)
+                    bin = 0;
+                hist_item.push_back(i1);
+                hist_bin.push_back(bin);
+            }
+        }
+    }
+    if (check_orientation) {
+        // ORBmatcher::ComputeThreeMaxima (src/ORBmatcher.cc:1698-1739)
+        int sizes[ORBX_HISTO_LENGTH] = {0};
+        for (int b : hist_bin)
+            sizes[b]++;
+        int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < ORBX_HISTO_LENGTH; i++) {
+            const int s = sizes[i];
+            if (s > max1) {
+                max3 = max2, max2 = max1, max1 = s;
+                i3 = i2, i2 = i1, i1 = i;
+            } else if (s > max2) {
+                max3 = max2, max2 = s;
+                i3 = i2, i2 = i;
+            } else if (s > max3) {
+                max3 = s;
+                i3 = i;
+            }
+        }
+        if (max2 < 0.1f * (float)max1)
+            i2 = -1, i3 = -1;
+        else if (max3 < 0.1f * (float)max1)
+            i3 = -1;
+        for (size_t k = 0; k < hist_item.size(); k++) {
+            const int b = hist_bin[k];
+            if (b == i1 || b == i2 || b == i3)
+                continue;
+            if (matches12[hist_item[k]] >= 0) {
+                matches12[hist_item[k]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    for (int i = 0; i < n1; i++)
+        if (matches12[i] >= 0) {
+            prev_matched[2 * i] = k2[matches12[i]].x;
+            prev_matched[2 * i + 1] = k2[matches12[i]].y;
+        }
+    return nmatches;
+}
+
+// ------------------------------------------------------------------ synthetic inputs
+
+static inline uint64_t splitmix64(uint64_t &s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+extern "C" int orbx_synth_image(uint64_t seed, int width, int height, int variant, uint8_t *dst, int stride_bytes)
+{
+    if (!dst || width < 1 || height < 1 || stride_bytes < width || variant < 0 || variant > 2)
+        return ORBX_E_ARG;
+    uint64_t s = seed;
+    for (int y = 0; y < height; y++)
+        memset(dst + (size_t)y * stride_bytes, 128, width);
+    if (variant != 1) {
+        const int nrect = (int)((long long)width * height / 300);
+        for (int r = 0; r < nrect; r++) {
+            const uint64_t a = splitmix64(s), b = splitmix64(s);
+            const int x0 = (int)(a % (uint64_t)width), y0 = (int)((a >> 32) % (uint64_t)height);
+            const int rw = 6 + (int)(b % 59), rh = 6 + (int)((b >> 16) % 59);
+            int gray = (int)((b >> 32) & 0xff);
+            if (variant == 2)
+                gray = 118 + gray % 21;
+            const int x1 = std::min(width, x0 + rw), y1 = std::min(height, y0 + rh);
+            for (int y = y0; y < y1; y++)
+                memset(dst + (size_t)y * stride_bytes + x0, gray, x1 - x0);
+        }
+    }
+    for (int y = 0; y < height; y++) {
+        uint8_t *row = dst + (size_t)y * stride_bytes;
+        for (int x = 0; x < width; x += 16) {
+            uint64_t r = splitmix64(s);
+            const int n = std::min(16, width - x);
+            for (int i = 0; i < n; i++, r >>= 4) {
+                const int v = (int)row[x + i] + (int)((r & 15) % 7) - 3;
+                row[x + i] = (uint8_t)std::min(255, std::max(0, v));
+            }
+        }
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_synth_descriptors(uint64_t seed, int64_t n, uint8_t *dst)
+{
+    if (!dst || n < 0)
+        return ORBX_E_ARG;
+    uint64_t s = seed;
+    uint64_t *p = reinterpret_cast<uint64_t *>(dst);
+    if ((reinterpret_cast<uintptr_t>(dst) & 7) == 0) {
+        for (int64_t i = 0; i < n * 4; i++)
+            p[i] = splitmix64(s);
+    } else {
+        for (int64_t i = 0; i < n * 4; i++) {
+            const uint64_t v = splitmix64(s);
+            memcpy(dst + i * 8, &v, 8);
+        }
+    }
+    return ORBX_OK;
+}

@@ -1,0 +1,103 @@
+// Internal declarations shared by the HIP translation units of liborbx.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "orbx.h"
+
+#define ORBX_MAX_LEVELS 16
+#define ORBX_EDGE 19        // EDGE_THRESHOLD of the reference (src/ORBextractor.cc:74)
+#define ORBX_BORDER 16      // EDGE_THRESHOLD-3: detection region is [16, cols-16) x [16, rows-16)
+#define ORBX_CELL_ORG 19    // first pixel FAST can report: border + 3
+#define ORBX_HALF_PATCH 15  // HALF_PATCH_SIZE (src/ORBextractor.cc:73)
+#define ORBX_MAX_ROOTS 64   // quadtree roots per level (round(width/height) of the detection region)
+
+// FAST / NMS tile produced by one workgroup
+#define ORBX_FT_W 64
+#define ORBX_FT_H 16
+
+struct OrbxLevel {
+    int w, h, pitch;  // level size and row pitch (bytes) inside a frame slab
+    int off;          // byte offset of the level inside a frame slab
+    int max_bx, max_by;  // w-16, h-16
+    int ncols, nrows, wcell, hcell;  // cell grid of src/ORBextractor.cc:834-840 (0 when the level is too small)
+    int cell_base;   // first cell of the level in the per-frame cell arrays
+    int tiles_x, tiles_y, tile_base;  // FAST tiles of the level in the per-frame tile numbering
+    int cand_base, cand_cap;          // segment of the per-frame candidate arrays
+    int quota;       // mnFeaturesPerLevel[level]
+    int n_ini;       // quadtree roots
+    float hx;        // root width
+    int node_cap;    // capacity of the node list of the level (max(quota, 4*n_ini) + 4)
+    int kp_base;     // segment of the per-frame kept-keypoint arrays
+    float scale;     // mvScaleFactor[level]
+    int patch_size;  // (int)(31*scale)
+    int xtab_off, ytab_off;  // offsets into the resize coefficient tables
+};
+
+struct OrbxGeom {
+    int nlevels, batch;
+    int ini_th, min_th;
+    int blur_variant;
+    int cells_per_frame, tiles_per_frame, cand_per_frame, kp_per_frame;
+    int out_cap;  // result rows per frame (== kp_per_frame)
+    int slab;     // bytes per frame in the level slabs
+    OrbxLevel lv[ORBX_MAX_LEVELS];
+};
+
+// horizontal / vertical bilinear coefficients of one destination column / row
+struct OrbxXCoef {
+    int sx;
+    short a0, a1;
+};
+struct OrbxYCoef {
+    int sy0, sy1;
+    short b0, b1;
+};
+
+// device status words written by kernels (index into the status array)
+enum { ORBX_ST_CAND_OVERFLOW = 0, ORBX_ST_NODE_OVERFLOW = 1, ORBX_ST_COUNT = 4 };
+
+struct OrbxBuffers {
+    uint8_t *pyr;     // [batch][slab] pyramid levels
+    uint8_t *blur;    // [batch][slab] blurred levels
+    uint8_t *nms;     // [batch][slab] per-cell local-maximum score maps
+    int *cell_cnt;    // [batch][cells_per_frame] candidates of each cell (bit 30 set: iniThFAST pass produced them)
+    int *cell_off;    // [batch][cells_per_frame] exclusive prefix inside the level
+    int *ncand;       // [batch][nlevels]
+    uint32_t *cand_xy;   // [batch][cand_per_frame] x | y<<16, relative to (16,16)
+    uint8_t *cand_resp;  // [batch][cand_per_frame]
+    uint16_t *cand_node; // [batch][cand_per_frame] quadtree scratch: node position of each candidate
+    uint32_t *kept_xy;   // [batch][kp_per_frame] x | y<<16 in level coordinates, quadtree list order
+    uint8_t *kept_resp;  // [batch][kp_per_frame]
+    int *nkept;          // [batch][nlevels]
+    orbx_keypoint *out_kp;  // [batch][out_cap]
+    uint8_t *out_desc;      // [batch][out_cap][32]
+    int *out_n;             // [batch]
+    int *status;            // [ORBX_ST_COUNT]
+    const OrbxXCoef *xtab;
+    const OrbxYCoef *ytab;
+};
+
+// kernel launchers (each enqueues on `s` and returns the hipGetLastError code)
+hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, const OrbxGeom &g, const OrbxBuffers &b,
+                              hipStream_t s);
+hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+hipError_t orbx_launch_fast_nms(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+hipError_t orbx_launch_cells(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+size_t orbx_octree_lds_bytes(int node_cap);
+
+// standalone quadtree run on caller-provided candidates (parity tests)
+hipError_t orbx_launch_octree_single(const uint32_t *d_xy, const uint8_t *d_resp, uint16_t *d_node, int n, int region_w,
+                                     int region_h, int quota, uint32_t *d_out_xy, uint8_t *d_out_resp, int *d_out_idx,
+                                     int *d_nout, int *d_status, int node_cap, hipStream_t s);
+
+// matcher launchers
+hipError_t orbx_launch_top2(const uint8_t *d_q, int nq, const uint8_t *d_db, int64_t ndb, int64_t idx_base,
+                            uint32_t *d_partial, int chunk_rows, int nchunks, int32_t *d_best, uint16_t *d_d1,
+                            uint16_t *d_d2, hipStream_t s);
+hipError_t orbx_launch_pair_dist(const uint8_t *d_a, const uint8_t *d_b, const int *d_pairs, int n, uint16_t *d_out,
+                                 hipStream_t s);

@@ -1,0 +1,116 @@
+"""Python mirror of the batched part of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h of the
+reference) on top of the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def synth_descriptors(seed, n):
+    out = np.zeros((n, 32), np.uint8)
+    L.check(L.lib().orbx_synth_descriptors(seed, n, L.ptr(out)), "orbx_synth_descriptors")
+    return out
+
+
+class ORBmatcher:
+    """ORBmatcher(nnratio=0.6, checkOri=True) (src/ORBmatcher.cc:41-43)."""
+
+    TH_HIGH = 100
+    TH_LOW = 50
+    HISTO_LENGTH = 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, *, device=0, max_queries=4096):
+        self.mfNNratio = float(nnratio)
+        self.mbCheckOrientation = bool(checkOri)
+        self._device = device
+        self._max_queries = max_queries
+        self._h = None
+        self._lib = L.lib()
+
+    def _handle(self):
+        if self._h is None:
+            h = C.c_void_p()
+            L.check(self._lib.orbx_matcher_create(self._device, self._max_queries, C.byref(h)), "orbx_matcher_create")
+            self._h = h
+        return self._h
+
+    def close(self):
+        if self._h is not None:
+            self._lib.orbx_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        L.check(self._lib.orbx_matcher_set_stream(self._handle(), C.c_void_p(hip_stream)), "orbx_matcher_set_stream")
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """Hamming distance of two 32-byte descriptors (src/ORBmatcher.cc:1744-1760); host only."""
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1)
+        b = np.ascontiguousarray(b, np.uint8).reshape(-1)
+        assert a.size == 32 and b.size == 32
+        return L.lib().orbx_descriptor_distance(L.ptr(a), L.ptr(b))
+
+    def match_top2(self, queries, db, idx_base=0):
+        """Brute-force best / second-best of each query row over db (host arrays).
+        Returns (best_idx int32, d1 uint16, d2 uint16)."""
+        q = np.ascontiguousarray(queries, np.uint8).reshape(-1, 32)
+        d = np.ascontiguousarray(db, np.uint8).reshape(-1, 32)
+        nq = q.shape[0]
+        best = np.zeros(nq, np.int32)
+        d1 = np.zeros(nq, np.uint16)
+        d2 = np.zeros(nq, np.uint16)
+        L.check(self._lib.orbx_match_top2(self._handle(), L.ptr(q), nq, L.ptr(d) if d.shape[0] else None,
+                                          d.shape[0], idx_base, L.ptr(best), L.ptr(d1), L.ptr(d2)),
+                "orbx_match_top2")
+        return best, d1, d2
+
+    def match_top2_device(self, d_q, nq, d_db, ndb, idx_base, d_best, d_d1, d_d2):
+        L.check(self._lib.orbx_match_top2_device(self._handle(), C.c_void_p(d_q), nq, C.c_void_p(d_db), ndb,
+                                                 idx_base, C.c_void_p(d_best), C.c_void_p(d_d1), C.c_void_p(d_d2)),
+                "orbx_match_top2_device")
+
+    @staticmethod
+    def merge_top2(best, d1, d2):
+        """Merges per-shard results of shape (nshards, nq) (shards in ascending index order)."""
+        best = np.ascontiguousarray(best, np.int32)
+        d1 = np.ascontiguousarray(d1, np.uint16)
+        d2 = np.ascontiguousarray(d2, np.uint16)
+        ns, nq = best.shape
+        ob, o1, o2 = np.zeros(nq, np.int32), np.zeros(nq, np.uint16), np.zeros(nq, np.uint16)
+        L.check(L.lib().orbx_top2_merge(ns, nq, L.ptr(best), L.ptr(d1), L.ptr(d2), L.ptr(ob), L.ptr(o1), L.ptr(o2)),
+                "orbx_top2_merge")
+        return ob, o1, o2
+
+    def ratio_test(self, d1, d2, th=None):
+        """Acceptance of src/ORBmatcher.cc:245-249 with this matcher's ratio."""
+        d1 = np.ascontiguousarray(d1, np.uint16)
+        d2 = np.ascontiguousarray(d2, np.uint16)
+        acc = np.zeros(d1.shape[0], np.uint8)
+        n = L.check(L.lib().orbx_ratio_test(d1.shape[0], L.ptr(d1), L.ptr(d2), self.TH_LOW if th is None else th,
+                                            self.mfNNratio, L.ptr(acc)), "orbx_ratio_test")
+        return acc.astype(bool), n
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds, vbPrevMatched, windowSize=10):
+        """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:433-549).
+        kps*: KEYPOINT_DTYPE arrays (the frames' mvKeysUn), desc*: (N,32) uint8, bounds = (mnMinX, mnMaxX,
+        mnMinY, mnMaxY), vbPrevMatched: (N1,2) float32, updated in place.
+        Returns (nmatches, vnMatches12, pair_count)."""
+        k1 = np.ascontiguousarray(kps1, L.KEYPOINT_DTYPE)
+        k2 = np.ascontiguousarray(kps2, L.KEYPOINT_DTYPE)
+        a = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
+        b = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        assert vbPrevMatched.dtype == np.float32 and vbPrevMatched.flags.c_contiguous
+        m12 = np.full(len(k1), -1, np.int32)
+        pairs = C.c_int64(0)
+        n = L.check(self._lib.orbx_search_for_initialization(
+            self._handle(), L.ptr(k1), L.ptr(a), len(k1), L.ptr(k2), L.ptr(b), len(k2), bounds[0], bounds[1],
+            bounds[2], bounds[3], L.ptr(vbPrevMatched), windowSize, self.mfNNratio, int(self.mbCheckOrientation),
+            L.ptr(m12), C.byref(pairs)), "orbx_search_for_initialization")
+        return n, m12, pairs.value

@@ -1,0 +1,168 @@
+"""GPU parity of the extractor: every stage of the HIP path, called through the C ABI, against the
+CPU oracle on the same seeded synthetic frames.  Bars: pyramid, blur, candidates, quadtree selection,
+keypoint coordinates/octaves/responses bit-exact; angles within 1e-3 degrees; descriptor bit
+mismatch <= 0.1 %."""
+import numpy as np
+import pytest
+
+import orbslam2_amd as orbx
+from orbslam2_amd.extractor import debug_octree
+
+from conftest import EUROC_STEREO, KITTI, KITTI_LOW, TUM
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x0B5EED00
+
+
+def make_extractor(p, w, h, batch=1, blur_variant=0):
+    return orbx.ORBextractor(p["nfeatures"], p["scale"], p["nlevels"], p["ini"], p["minth"], max_width=w,
+                             max_height=h, max_batch=batch, blur_variant=blur_variant)
+
+
+def oracle_extract(oracle, img, p, blur_variant=0, trace=False):
+    return oracle.extract(img, p["nfeatures"], p["scale"], p["nlevels"], p["ini"], p["minth"], blur_variant, trace)
+
+
+def compare_frame(kg, dg, ko, do):
+    assert len(kg) == len(ko)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(kg[f], ko[f]), f
+    if len(kg) == 0:
+        return 0.0
+    dang = np.abs(kg["angle"].astype(np.float64) - ko["angle"].astype(np.float64))
+    dang = np.minimum(dang, 360.0 - dang)
+    assert dang.max() <= 1e-3, dang.max()
+    bits = np.unpackbits(dg ^ do).sum()
+    frac = bits / (dg.size * 8.0)
+    assert frac <= 1e-3, frac
+    return frac
+
+
+@pytest.mark.parametrize("w,h,p,variant", [
+    (640, 480, TUM, 0),
+    (1241, 376, KITTI, 0),
+    (752, 480, TUM, 0),
+    (640, 480, TUM, 2),
+    (1241, 376, KITTI_LOW, 2),
+    (752, 480, EUROC_STEREO, 0),
+    (333, 217, TUM, 0),
+])
+def test_stages_and_frame(oracle, w, h, p, variant):
+    img = orbx.synth_image(SEED + 7 * variant, w, h, variant)
+    ex = make_extractor(p, w, h)
+    kg, dg = ex(img)
+    ko, do, tr = oracle_extract(oracle, img, p, trace=True)
+    for l in range(p["nlevels"]):
+        lev = ex.pyramid_level(0, l)
+        assert lev.shape == tr["levels"][l].shape
+        assert np.array_equal(lev, tr["levels"][l]), "pyramid level %d" % l
+        xs, ys, rs = ex.debug_candidates(0, l)
+        oxs, oys, ors = oracle.level_candidates(tr["levels"][l], p["ini"], p["minth"])
+        assert len(xs) == len(oxs), "candidate count level %d: %d vs %d" % (l, len(xs), len(oxs))
+        assert np.array_equal(xs, oxs) and np.array_equal(ys, oys) and np.array_equal(rs, ors), l
+        if tr["blur"][l] is not None:
+            assert np.array_equal(ex.debug_level_map(1, 0, l), tr["blur"][l]), "blur level %d" % l
+    _, per_level = ex.batch_counts()
+    assert list(per_level[0]) == tr["nkeep"]
+    compare_frame(kg, dg, ko, do)
+    ex.close()
+
+
+def test_blur_variant_cv2(oracle):
+    img = orbx.synth_image(SEED + 3, 640, 480, 0)
+    ex = make_extractor(TUM, 640, 480, blur_variant=1)
+    kg, dg = ex(img)
+    ko, do, tr = oracle_extract(oracle, img, TUM, blur_variant=1, trace=True)
+    assert np.array_equal(ex.debug_level_map(1, 0, 0), tr["blur"][0])
+    compare_frame(kg, dg, ko, do)
+
+
+def test_mono_init_extractor_4000(oracle):
+    # the initialisation extractor asks for 2*nFeatures (src/Tracking.cc:128)
+    p = dict(KITTI, nfeatures=4000)
+    img = orbx.synth_image(SEED + 11, 1241, 376, 0)
+    ex = make_extractor(p, 1241, 376)
+    kg, dg = ex(img)
+    ko, do = oracle_extract(oracle, img, p)
+    compare_frame(kg, dg, ko, do)
+
+
+def test_flat_and_empty(oracle):
+    ex = make_extractor(TUM, 640, 480)
+    flat = orbx.synth_image(SEED, 640, 480, 1)
+    k, d = ex(flat)
+    ko, do = oracle_extract(oracle, flat, TUM)
+    assert len(k) == 0 and d.shape == (0, 32) and len(ko) == 0
+    assert ex(np.zeros((0, 0), np.uint8)) == (None, None)
+    # constant image: no corners anywhere
+    k, d = ex(np.full((480, 640), 77, np.uint8))
+    assert len(k) == 0
+
+
+def test_tiny_images(oracle):
+    # small levels lose their cell grid (fewer than 30 px of detection region): no keypoints there
+    for (w, h) in [(96, 80), (70, 64), (40, 40)]:
+        img = orbx.synth_image(SEED + w, w, h, 0)
+        ex = make_extractor(TUM, w, h)
+        kg, dg = ex(img)
+        ko, do = oracle_extract(oracle, img, TUM)
+        compare_frame(kg, dg, ko, do)
+        ex.close()
+
+
+def test_strided_input_and_reuse(oracle):
+    # a row stride larger than the width, and two different sizes through one handle
+    ex = make_extractor(TUM, 800, 600)
+    for (w, h, stride) in [(640, 480, 704), (800, 600, 800), (641, 479, 1000)]:
+        buf = orbx.synth_image(SEED + w, w, h, 0, stride=stride)
+        kg, dg = ex(buf[:, :w])
+        ko, do = oracle_extract(oracle, np.ascontiguousarray(buf[:, :w]), TUM)
+        compare_frame(kg, dg, ko, do)
+
+
+def test_batch_matches_single(oracle):
+    w, h, B = 752, 480, 6
+    imgs = [orbx.synth_image(SEED + i, w, h, 0 if i % 3 else 2) for i in range(B)]
+    ex = make_extractor(TUM, w, h, batch=B)
+    ex.extract_batch_host(imgs)
+    n, _ = ex.batch_counts()
+    for i in range(B):
+        kg, dg = ex.batch_download(i)
+        ko, do = oracle_extract(oracle, imgs[i], TUM)
+        assert n[i] == len(ko)
+        compare_frame(kg, dg, ko, do)
+
+
+def test_padded_pyramid(oracle):
+    img = orbx.synth_image(SEED, 320, 240, 0)
+    ex = make_extractor(TUM, 320, 240)
+    ex(img, pyramid_border=19)
+    for l, padded in enumerate(ex.mvImagePyramid):
+        inner = ex.pyramid_level(0, l)
+        ref = np.pad(inner, 19, mode="reflect")  # numpy 'reflect' == BORDER_REFLECT_101
+        assert np.array_equal(padded, ref)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_octree_random(oracle, seed):
+    rng = np.random.default_rng(seed)
+    rw, rh = [(1209, 344), (608, 448), (300, 200), (1209, 344), (720, 448), (95, 90)][seed]
+    n = [5000, 1500, 40, 20000, 3000, 300][seed]
+    quota = [434, 217, 60, 869, 1, 122][seed]
+    # distinct pixels, clustered to force deep and uneven subdivision
+    pts = set()
+    while len(pts) < n:
+        if rng.random() < 0.5:
+            cx, cy = rng.integers(0, rw), rng.integers(0, rh)
+            x = int(np.clip(cx + rng.normal(0, 6), 0, rw - 1))
+            y = int(np.clip(cy + rng.normal(0, 6), 0, rh - 1))
+        else:
+            x, y = int(rng.integers(0, rw)), int(rng.integers(0, rh))
+        pts.add((x, y))
+    pts = np.array(sorted(pts, key=lambda t: (t[1], t[0])), np.int32)
+    xs, ys = pts[:, 0].copy(), pts[:, 1].copy()
+    resp = rng.integers(7, 60, size=n).astype(np.int32)  # many ties
+    got = debug_octree(xs, ys, resp, rw, rh, quota)
+    want = oracle.distribute_octree(xs, ys, resp, 16, 16 + rw, 16, 16 + rh, quota)
+    assert np.array_equal(got, want)

@@ -1,0 +1,125 @@
+"""GPU parity of the matcher through the C ABI: indices and distances bit-exact against the oracle."""
+import numpy as np
+import pytest
+
+import orbslam2_amd as orbx
+
+pytestmark = pytest.mark.gpu
+
+
+def make_db(n, nq, seed=1):
+    """Config-4 style data: random database, queries = database rows with 0..80 flipped bits, and a
+    near-duplicate next to every tenth source row."""
+    db = orbx.synth_descriptors(seed, n)
+    rng = np.random.default_rng(seed + 1)
+    step = max(1, n // nq)
+    q = np.zeros((nq, 32), np.uint8)
+    for i in range(nq):
+        row = (i * step) % n
+        bits = np.unpackbits(db[row])
+        k = rng.integers(0, 81)
+        flip = rng.choice(256, size=k, replace=False)
+        bits[flip] ^= 1
+        q[i] = np.packbits(bits)
+        if i % 10 == 0 and row + 1 < n:
+            b2 = np.unpackbits(db[row])
+            b2[rng.choice(256, size=4, replace=False)] ^= 1
+            db[row + 1] = np.packbits(b2)
+    return db, q
+
+
+@pytest.mark.parametrize("ndb,nq", [(1, 1), (3, 5), (255, 64), (4096, 300), (100003, 2000)])
+def test_top2_vs_oracle(oracle, ndb, nq):
+    db, q = make_db(ndb, nq)
+    m = orbx.ORBmatcher(0.75)
+    best, d1, d2 = m.match_top2(q, db)
+    ob, o1, o2 = oracle.match_top2(q, db)
+    assert np.array_equal(best, ob)
+    assert np.array_equal(d1, o1)
+    assert np.array_equal(d2, o2)
+    acc, n = m.ratio_test(d1, d2)
+    want = [oracle.lib().orc_ratio_accept(int(a), int(b), 50, 0.75) for a, b in zip(o1, o2)]
+    assert list(acc.astype(int)) == want and n == sum(want)
+
+
+def test_top2_ties_and_extremes(oracle):
+    # duplicates (first index must win), an all-different row (distance 256 never becomes best)
+    q = np.zeros((3, 32), np.uint8)
+    q[1] = 0xFF
+    q[2, :4] = 0xF0
+    db = np.zeros((10, 32), np.uint8)
+    db[0] = 0xFF
+    db[3] = 0x0F
+    db[4:] = 0xFF
+    m = orbx.ORBmatcher()
+    best, d1, d2 = m.match_top2(q, db)
+    ob, o1, o2 = oracle.match_top2(q, db)
+    assert np.array_equal(best, ob) and np.array_equal(d1, o1) and np.array_equal(d2, o2)
+    only = np.full((1, 32), 0xFF, np.uint8)
+    best, d1, d2 = m.match_top2(np.zeros((1, 32), np.uint8), only)
+    assert best[0] == -1 and d1[0] == 256 and d2[0] == 256
+    # empty database
+    best, d1, d2 = m.match_top2(q, np.zeros((0, 32), np.uint8))
+    assert list(best) == [-1, -1, -1] and list(d1) == [256] * 3
+
+
+def test_sharded_merge_equals_single_pass(oracle):
+    db, q = make_db(50000, 500, seed=5)
+    m = orbx.ORBmatcher(0.75)
+    shards = 8
+    per = (len(db) + shards - 1) // shards
+    bs, d1s, d2s = [], [], []
+    for s in range(shards):
+        b, a1, a2 = m.match_top2(q, db[s * per:(s + 1) * per], idx_base=s * per)
+        bs.append(b), d1s.append(a1), d2s.append(a2)
+    mb, m1, m2 = m.merge_top2(np.stack(bs), np.stack(d1s), np.stack(d2s))
+    ob, o1, o2 = oracle.match_top2(q, db)
+    assert np.array_equal(mb, ob) and np.array_equal(m1, o1) and np.array_equal(m2, o2)
+
+
+def test_full_size_properties():
+    """Config-4 size (2000 x 1M): checked through properties instead of the CPU loop: every query was
+    cut from a known row, so a query with few flipped bits must find it; d1 <= d2; shard sum rule."""
+    n, nq = 1_000_000, 2000
+    db = orbx.synth_descriptors(1, n)
+    rng = np.random.default_rng(2)
+    rows = np.arange(nq) * 500
+    q = db[rows].copy()
+    flips = rng.integers(0, 60, size=nq)
+    for i in range(nq):
+        bits = np.unpackbits(q[i])
+        bits[rng.choice(256, size=flips[i], replace=False)] ^= 1
+        q[i] = np.packbits(bits)
+    m = orbx.ORBmatcher(0.75)
+    best, d1, d2 = m.match_top2(q, db)
+    assert np.array_equal(best, rows)          # random rows sit ~128 bits away; the source row wins
+    assert np.array_equal(d1, flips.astype(np.uint16))
+    assert (d1 <= d2).all() and (d2 > 60).all() and (d2 <= 128).all()
+    half = n // 2
+    b0 = m.match_top2(q, db[:half])
+    b1 = m.match_top2(q, db[half:], idx_base=half)
+    mb, m1, m2 = m.merge_top2(np.stack([b0[0], b1[0]]), np.stack([b0[1], b1[1]]), np.stack([b0[2], b1[2]]))
+    assert np.array_equal(mb, best) and np.array_equal(m1, d1) and np.array_equal(m2, d2)
+
+
+def test_search_for_initialization_vs_oracle(oracle):
+    w, h = 1241, 376
+    ex = orbx.ORBextractor(2000, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    img1 = orbx.synth_image(0x0B5EED00, w, h, 0)
+    # second frame: the first shifted by a few pixels plus fresh noise -> real matches
+    img2 = np.roll(img1, (3, 5), axis=(0, 1))
+    noise = np.random.default_rng(3).integers(-2, 3, size=img2.shape)
+    img2 = np.clip(img2.astype(np.int16) + noise, 0, 255).astype(np.uint8)
+    k1, d1 = ex(img1)
+    k2, d2 = ex(img2)
+    bounds = (0.0, float(w), 0.0, float(h))
+    for ratio, ori, win in [(0.9, True, 100), (0.9, False, 100), (0.6, True, 30)]:
+        prev_g = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32).copy()
+        prev_o = prev_g.copy()
+        m = orbx.ORBmatcher(ratio, ori)
+        n, m12, pairs = m.SearchForInitialization(k1, d1, k2, d2, bounds, prev_g, win)
+        on, om12, opairs = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev_o, win, ratio, ori)
+        assert n == on and pairs == opairs
+        assert np.array_equal(m12, om12)
+        assert np.array_equal(prev_g, prev_o)
+        assert n > 50
