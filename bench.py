@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X ORB front end.
+
+A step = one pass of the extractor over one batch of synthetic KITTI-shape frames (1241x376,
+2000 keypoints per frame, 8 levels, scale 1.2, FAST thresholds 20/7) that already sit in HBM.
+`value` is frames per second over all ranks.  One process per GPU; frames are independent, so
+ranks share nothing on the data path (weak scaling); torch.distributed only provides the barrier
+and the max-over-ranks of the elapsed time.
+
+Extra objects on the JSON line:
+  roofline      dominant extractor kernel: algorithmic bytes per launch / its HIP-event duration vs 8 TB/s
+  cpu_baseline  the CPU oracle (oracle/, a scalar restatement of the reference) on a bounded sample
+  stages        per-stage milliseconds per batch (HIP events on the extractor's stream)
+  hamming       brute-force top-2 of 2000 queries against a 1M-descriptor database on this GPU
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+# INT32 vector lanes: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz; one 256-bit pair = 8 XOR + 8 popcount-accumulate
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9
+OPS_PER_PAIR = 16
+
+WORKLOADS = {
+    # name: (width, height, nfeatures, frames per batch)
+    "kitti_1241x376_2000kp": (1241, 376, 2000, 128),
+    "euroc_752x480_1000kp": (752, 480, 1000, 128),
+    "tum_640x480_1000kp": (640, 480, 1000, 128),
+}
+
+
+def level_sizes(w, h, nlevels=8, scale=1.2):
+    s = np.float32(1.0)
+    out = []
+    for _ in range(nlevels):
+        inv = np.float32(1.0) / s
+        out.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+        s = np.float32(np.float64(s) * np.float64(np.float32(scale)))
+    return out
+
+
+def algorithmic_bytes(w, h, n_kp):
+    """Compulsory bytes per frame of each stage (every stage reads its input once and writes its
+    output once): P = pyramid pixels, I = level-0 pixels, p7 = last-level pixels, N = keypoints."""
+    lv = level_sizes(w, h)
+    P = sum(a * b for a, b in lv)
+    I = lv[0][0] * lv[0][1]
+    p7 = lv[-1][0] * lv[-1][1]
+    per_stage = {
+        "ingest": 0.0,
+        "resize": float((P - p7) + (P - I)),
+        "fast_nms": float(P),
+        "cells": 0.0,
+        "octree": 0.0,
+        "blur": float(2 * P),
+        "describe": float((749 + 512 + 60) * n_kp),
+    }
+    return per_stage, float(5 * P - I - p7 + 1321 * n_kp)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kitti_1241x376_2000kp", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import orbslam2_amd as orbx
+
+    w, h, nfeat, batch = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    # synthetic frames, different on every rank, generated on the host and uploaded once
+    stride = w
+    host = np.zeros((batch, h, stride), np.uint8)
+    for f in range(batch):
+        host[f] = orbx.synth_image(0x0B5EED00 + rank * 100003 + f, w, h, 0, stride=stride)
+    frames = torch.from_numpy(host).cuda()
+    stream = torch.cuda.Stream()
+    ex = orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch, device=local_rank)
+    ex.set_stream(stream.cuda_stream)
+
+    def step():
+        ex.extract_batch_device(frames.data_ptr(), batch, w, h, stride, h * stride)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ex.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    ex.profile(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    counts, _ = ex.batch_counts()
+    n_kp = float(np.mean(counts))
+    stage_ms, nprof = ex.stage_times()
+    stage_ms = {k: v / max(nprof, 1) for k, v in stage_ms.items()}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    frames_total = world * batch * args.steps
+    fps = frames_total / elapsed
+    per_stage_bytes, frame_bytes = algorithmic_bytes(w, h, n_kp)
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    dom_bytes = per_stage_bytes[dom] * batch
+    dom_s = stage_ms[dom] * 1e-3
+    achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel_ms_per_launch": round(stage_ms[dom], 4),
+                "algorithmic_bytes_per_launch": dom_bytes,
+                "pipeline_achieved_GBs": round(fps / world * frame_bytes / 1e9, 2),
+                "pipeline_frac": round(fps / world * frame_bytes / 1e9 / HBM_PEAK_GBS, 5)}
+
+    out = {
+        "metric": "ORB frames/s @KITTI 1241x376 2000 kp (1/8 GPU); Hamming matches/s; % roofline",
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "nfeatures": nfeat, "nlevels": 8,
+                   "scale_factor": 1.2, "ini_th_fast": 20, "min_th_fast": 7, "mean_keypoints_per_frame": n_kp,
+                   "parallelism": "frame-batch shards, no collective"},
+        "roofline": roofline,
+        "stages_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+    }
+
+    if world == 1 and not args.no_hamming:
+        out["hamming"] = bench_hamming(orbx, torch, stream)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(host, w, nfeat, args.cpu_seconds)
+        out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_hamming(orbx, torch, stream):
+    """2000 queries x 1M database rows resident in HBM (one GPU's view of the sharded relocalisation match)."""
+    nq, ndb = 2000, 1_000_000
+    db = torch.from_numpy(orbx.synth_descriptors(1, ndb)).cuda()
+    q = db[:: ndb // nq][:nq].clone()
+    q[:, 0] ^= 0x5A
+    best = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    m = orbx.ORBmatcher(0.75)
+    m.set_stream(stream.cuda_stream)
+
+    def run():
+        m.match_top2_device(q.data_ptr(), nq, db.data_ptr(), ndb, 0, best.data_ptr(), d1.data_ptr(), d2.data_ptr())
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    reps = 20
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    pairs = nq * ndb
+    rate = pairs / sec
+    peak_pairs = VALU_LANE_OPS_PER_S / OPS_PER_PAIR
+    ok = bool((best.cpu().numpy() == np.arange(nq) * (ndb // nq)).all())
+    return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
+            "self_check": ok,
+            "roofline": {"bound": "valu-int32", "achieved": round(rate * OPS_PER_PAIR / 1e12, 3),
+                         "peak": round(VALU_LANE_OPS_PER_S / 1e12, 3), "unit": "Tlane-op/s",
+                         "frac": round(rate / peak_pairs, 4)}}
+
+
+def cpu_baseline(host_frames, w, nfeat, budget_s):
+    """The oracle (scalar C restatement of the reference extractor) on one host core, same frames."""
+    from oracle import pyoracle as orc
+
+    orc.lib()
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        img = np.ascontiguousarray(host_frames[n % len(host_frames)][:, :w])
+        orc.extract(img, nfeat, 1.2, 8, 20, 7)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 2000:
+            break
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d KITTI-shape synthetic frames in %.1f s, one thread, scalar C (no SIMD FAST/resize/blur "
+                      "as OpenCV has, so pessimistic for the reference)" % (n, dt)}
+
+
+if __name__ == "__main__":
+    main()

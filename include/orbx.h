@@ -115,6 +115,16 @@ int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *keypoints,
 int orbx_batch_device_results(orbx_extractor *ex, const orbx_keypoint **d_keypoints, const uint8_t **d_descriptors,
                               const int32_t **d_counts, int *max_keypoints);
 
+/* Per-stage device time of the batches extracted while profiling is enabled, measured with HIP
+ * events recorded on the handle's stream around each stage.  The reference has no counterpart
+ * (it only wall-clocks whole Track calls, Examples/Stereo/stereo_kitti.cc:80-97).
+ * Stages: 0 ingest (copy of the caller's frames into level 0), 1 resize (levels 1..n-1),
+ * 2 fast_nms, 3 cells (count, scan, emit), 4 octree, 5 blur, 6 describe (orientation, rBRIEF, output). */
+#define ORBX_NSTAGES 7
+const char *orbx_stage_name(int stage);
+int orbx_extractor_profile(orbx_extractor *ex, int enable); /* enabling clears earlier samples */
+int orbx_extractor_stage_times(orbx_extractor *ex, float *ms_sum /* ORBX_NSTAGES */, int *nbatches);
+
 /* replaces reads of the public member mvImagePyramid (include/ORBextractor.h:85; read by
  * src/Frame.cc:541,631,643,648): copies level `level` of frame `frame` of the last batch into
  * dst (dst_stride bytes per row; dst may be NULL to query the size).  border > 0 additionally
@@ -131,6 +141,11 @@ int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int level, uin
  * relative to (16,16), reference order.  Returns the count through *n_out. */
 int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, int *xs, int *ys, int *resp, int cap,
                           int *n_out);
+/* Quadtree distribution alone (ORBextractor::DistributeOctTree, src/ORBextractor.cc:578-813) on n
+ * host candidates with coordinates relative to a region_w x region_h detection region and quota N:
+ * out_idx receives the kept candidate indices in list order. */
+int orbx_debug_octree(int device, const int *xs, const int *ys, const int *resp, int n, int region_w, int region_h,
+                      int quota, int *out_idx, int cap, int *n_out);
 
 /* ---------------------------------------------------------------- matcher */
 

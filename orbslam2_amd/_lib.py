@@ -11,6 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbx.so")
 
+NSTAGES = 7
 OK, E_ARG, E_HIP, E_CAPACITY, E_GEOMETRY, E_NODEVICE, E_STATE = 0, -1, -2, -3, -4, -5, -6
 
 
@@ -58,6 +59,9 @@ SIGNATURES = {
     "orbx_batch_counts": (C.c_int, [_P, _i32p, _i32p]),
     "orbx_batch_download": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _i32p]),
     "orbx_batch_device_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _i32p]),
+    "orbx_stage_name": (C.c_char_p, [C.c_int]),
+    "orbx_extractor_profile": (C.c_int, [_P, C.c_int]),
+    "orbx_extractor_stage_times": (C.c_int, [_P, _f32p, _i32p]),
     "orbx_pyramid_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _i32p, _i32p]),
     "orbx_debug_level_map": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "orbx_debug_candidates": (C.c_int, [_P, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int, _i32p]),

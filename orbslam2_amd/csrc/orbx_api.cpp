@@ -55,7 +55,30 @@ struct orbx_extractor {
     OrbxYCoef *d_ytab;
     int xtab_cap, ytab_cap;
     std::vector<int> h_counts, h_nkept;
+    bool profiling;
+    std::vector<hipEvent_t> prof_events;  // ORBX_NSTAGES+1 events per profiled batch
+    size_t prof_used;
 };
+
+static const char *const k_stage_names[ORBX_NSTAGES] = {"ingest", "resize", "fast_nms", "cells",
+                                                        "octree", "blur",   "describe"};
+extern "C" const char *orbx_stage_name(int i) { return i >= 0 && i < ORBX_NSTAGES ? k_stage_names[i] : ""; }
+
+// records the boundary event `idx` of the current profiled batch
+static hipError_t prof_mark(orbx_extractor *ex, int idx)
+{
+    if (!ex->profiling)
+        return hipSuccess;
+    const size_t at = ex->prof_used * (ORBX_NSTAGES + 1) + idx;
+    while (ex->prof_events.size() <= at) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess)
+            return rc;
+        ex->prof_events.push_back(e);
+    }
+    return hipEventRecord(ex->prof_events[at], ex->stream);
+}
 
 static inline int round_half_even(float v) { return (int)lrintf(v); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
@@ -259,6 +282,8 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->device = p.device;
     ex->geom_w = ex->geom_h = 0;
     ex->have_batch = false;
+    ex->profiling = false;
+    ex->prof_used = 0;
     ex->own_stream = ex->stream = nullptr;
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
@@ -324,6 +349,8 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *ex)
         return;
     (void)hipSetDevice(ex->device);
     (void)hipStreamSynchronize(ex->stream);
+    for (hipEvent_t e : ex->prof_events)
+        (void)hipEventDestroy(e);
     free_buffers(ex);
     if (ex->own_stream)
         (void)hipStreamDestroy(ex->own_stream);
@@ -407,13 +434,22 @@ static int run_pipeline(orbx_extractor *ex)
     const OrbxBuffers &b = ex->buf;
     hipStream_t s = ex->stream;
     HIP_TRY(hipMemsetAsync(b.status, 0, ORBX_ST_COUNT * sizeof(int), s));
+    HIP_TRY(prof_mark(ex, 1));
     for (int l = 1; l < g.nlevels; l++)
         HIP_TRY(orbx_launch_resize(l, g, b, s));
+    HIP_TRY(prof_mark(ex, 2));
     HIP_TRY(orbx_launch_fast_nms(g, b, s));
+    HIP_TRY(prof_mark(ex, 3));
     HIP_TRY(orbx_launch_cells(g, b, s));
+    HIP_TRY(prof_mark(ex, 4));
     HIP_TRY(orbx_launch_octree(g, b, s));
+    HIP_TRY(prof_mark(ex, 5));
     HIP_TRY(orbx_launch_blur(g, b, s));
+    HIP_TRY(prof_mark(ex, 6));
     HIP_TRY(orbx_launch_describe(g, b, s));
+    HIP_TRY(prof_mark(ex, 7));
+    if (ex->profiling)
+        ex->prof_used++;
     ex->have_batch = true;
     return ORBX_OK;
 }
@@ -426,6 +462,7 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_im
     int rc = prepare(ex, batch, width, height);
     if (rc != ORBX_OK)
         return rc;
+    HIP_TRY(prof_mark(ex, 0));
     HIP_TRY(orbx_launch_ingest(d_images, stride_bytes, frame_stride_bytes, ex->geom, ex->buf, ex->stream));
     return run_pipeline(ex);
 }
@@ -439,6 +476,7 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
     if (rc != ORBX_OK)
         return rc;
     const OrbxLevel &L0 = ex->geom.lv[0];
+    HIP_TRY(prof_mark(ex, 0));
     for (int f = 0; f < batch; f++) {
         if (!images[f])
             return ORBX_E_ARG;
@@ -446,6 +484,36 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
                                  width, height, hipMemcpyHostToDevice, ex->stream));
     }
     return run_pipeline(ex);
+}
+
+extern "C" int orbx_extractor_profile(orbx_extractor *ex, int enable)
+{
+    if (!ex)
+        return ORBX_E_ARG;
+    ex->profiling = enable != 0;
+    if (enable)
+        ex->prof_used = 0;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_stage_times(orbx_extractor *ex, float *ms_sum, int *nbatches)
+{
+    if (!ex || !ms_sum || !nbatches)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(ex->device));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    for (int i = 0; i < ORBX_NSTAGES; i++)
+        ms_sum[i] = 0.f;
+    for (size_t b = 0; b < ex->prof_used; b++) {
+        const hipEvent_t *ev = &ex->prof_events[b * (ORBX_NSTAGES + 1)];
+        for (int i = 0; i < ORBX_NSTAGES; i++) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            ms_sum[i] += ms;
+        }
+    }
+    *nbatches = (int)ex->prof_used;
+    return ORBX_OK;
 }
 
 extern "C" int orbx_batch_counts(orbx_extractor *ex, int *n_per_frame, int *n_per_level)

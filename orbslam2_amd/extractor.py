@@ -143,6 +143,18 @@ class ORBextractor:
                 "orbx_batch_device_results")
         return kp.value, de.value, cn.value, cap.value
 
+    def profile(self, enable=True):
+        L.check(self._lib.orbx_extractor_profile(self._h, int(enable)), "orbx_extractor_profile")
+
+    def stage_times(self):
+        """Returns ({stage name: summed ms}, number of profiled batches); synchronises the stream."""
+        ms = np.zeros(L.NSTAGES, np.float32)
+        n = C.c_int(0)
+        L.check(self._lib.orbx_extractor_stage_times(self._h, ms.ctypes.data_as(C.POINTER(C.c_float)), C.byref(n)),
+                "orbx_extractor_stage_times")
+        names = [self._lib.orbx_stage_name(i).decode() for i in range(L.NSTAGES)]
+        return dict(zip(names, ms.tolist())), n.value
+
     # ---- mvImagePyramid (include/ORBextractor.h:85) and stage outputs ----
     def level_size(self, frame, level):
         w, h = C.c_int(0), C.c_int(0)
