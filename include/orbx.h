@@ -116,11 +116,13 @@ int orbx_batch_device_results(orbx_extractor *ex, const orbx_keypoint **d_keypoi
                               const int32_t **d_counts, int *max_keypoints);
 
 /* Per-stage device time of the batches extracted while profiling is enabled, measured with HIP
- * events recorded on the handle's stream around each stage.  The reference has no counterpart
+ * events recorded around each stage on the stream it runs on (the blur runs on a second stream
+ * beside detection and distribution, so stage times can overlap).  The reference has no counterpart
  * (it only wall-clocks whole Track calls, Examples/Stereo/stereo_kitti.cc:80-97).
  * Stages: 0 ingest (copy of the caller's frames into level 0), 1 resize (levels 1..n-1),
- * 2 fast_nms, 3 cells (count, scan, emit), 4 octree, 5 blur, 6 describe (orientation, rBRIEF, output). */
-#define ORBX_NSTAGES 7
+ * 2 fast (score, per-cell non-maximum suppression, candidate append), 3 octree (threshold fallback and
+ * quadtree distribution), 4 blur, 5 describe (orientation, rBRIEF, output). */
+#define ORBX_NSTAGES 6
 const char *orbx_stage_name(int stage);
 int orbx_extractor_profile(orbx_extractor *ex, int enable); /* enabling clears earlier samples */
 int orbx_extractor_stage_times(orbx_extractor *ex, float *ms_sum /* ORBX_NSTAGES */, int *nbatches);
@@ -134,11 +136,11 @@ int orbx_extractor_stage_times(orbx_extractor *ex, float *ms_sum /* ORBX_NSTAGES
 int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, int border, uint8_t *dst, int dst_stride,
                        int *width, int *height);
 
-/* Stage outputs of the last batch, for parity tests.  what: 0 = FAST/NMS score map of a level
- * (u8, level-sized, 0 where the pixel is not a per-cell local maximum), 1 = blurred level. */
+/* Stage output of the last batch, for parity tests.  what: 1 = blurred level (u8, level-sized). */
 int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int level, uint8_t *dst, int dst_stride);
 /* Candidate list of a level before the quadtree (src/ORBextractor.cc:880-890): coordinates
- * relative to (16,16), reference order.  Returns the count through *n_out. */
+ * relative to (16,16), sorted into the reference's order (cells row-major, row-major inside a cell),
+ * after the per-cell iniThFAST -> minThFAST decision.  Returns the count through *n_out. */
 int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, int *xs, int *ys, int *resp, int cap,
                           int *n_out);
 /* Quadtree distribution alone (ORBextractor::DistributeOctTree, src/ORBextractor.cc:578-813) on n

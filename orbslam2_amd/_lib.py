@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbx.so")
 
-NSTAGES = 7
+NSTAGES = 6
 OK, E_ARG, E_HIP, E_CAPACITY, E_GEOMETRY, E_NODEVICE, E_STATE = 0, -1, -2, -3, -4, -5, -6
 
 

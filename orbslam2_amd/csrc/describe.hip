@@ -25,15 +25,18 @@ __device__ __forceinline__ int reflect101(int i, int n)
 
 #define BL_W 64
 #define BL_H 16
-#define BL_SW (BL_W + 8)  // staged columns tx0-4 .. tx0+67 (word aligned; 3 needed each side)
-#define BL_SH (BL_H + 6)
+#define BL_SW (BL_W + 8)   // staged columns tx0-4 .. tx0+67 (word aligned; 3 needed each side)
+#define BL_SH (BL_H + 6)   // staged rows ty0-3 .. ty0+18
+#define BL_HP (BL_W + 4)   // u16 pitch of the horizontal sums (8-byte aligned rows, offset banks)
 
 // Separable fixed-point filter: horizontal sums fit 16 bits (kernel sum <= 257), the vertical pass
 // rounds with +32768 and shifts by 16; variant 1 (kernel sum 257) saturates to 255.
+// Every thread produces four adjacent pixels: the horizontal pass is two 4-byte dot products per
+// pixel on byte windows cut from three staged words, the vertical pass seven 16-bit multiply-adds.
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, BlurArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[BL_SH * BL_SW];
-    __shared__ uint16_t hs[BL_SH * BL_W];
+    __shared__ __attribute__((aligned(16))) uint16_t hs[BL_SH * BL_HP];
     const int f = blockIdx.y;
     int lvl = 0;
     while (lvl + 1 < a.nlevels && (int)blockIdx.x >= a.tile_base[lvl + 1])
@@ -43,7 +46,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
     const uint8_t *src = pyr + (size_t)f * a.slab + a.off[lvl];
     uint8_t *dst = blur + (size_t)f * a.slab + a.off[lvl];
-    const int k0 = 18, k1 = 34, k2 = a.variant ? 49 : 48, k3 = a.variant ? 55 : 56;
+    const uint32_t k0 = 18, k1 = 34, k2 = a.variant ? 49 : 48, k3 = a.variant ? 55 : 56;
+    const uint32_t kA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);  // taps 0..3
+    const uint32_t kB = k2 | (k1 << 8) | (k0 << 16);               // taps 4..6
 
     const bool interior = tx0 >= 4 && tx0 + BL_W + 4 <= w && ty0 >= 3 && ty0 + BL_H + 3 <= h;
     if (interior) {
@@ -60,22 +65,42 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < BL_SH * BL_W; i += 256) {
-        const int r = i / BL_W, c = i % BL_W;
-        const uint8_t *p = &img[r * BL_SW + c + 1];  // p[0..6] = columns x-3 .. x+3
-        hs[i] = (uint16_t)(k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3]);
+    for (int i = threadIdx.x; i < BL_SH * (BL_W / 4); i += 256) {
+        const int r = i / (BL_W / 4), cg = i % (BL_W / 4);
+        // staged bytes 4cg .. 4cg+11 hold columns x-4 .. x+7 of the group's first pixel x
+        const uint32_t *wp = reinterpret_cast<const uint32_t *>(&img[r * BL_SW + cg * 4]);
+        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+        uint32_t hv[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            // pixel x+o: taps at staged bytes o+1 .. o+7
+            const uint32_t lo = o == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, o + 1);            // bytes o+1..o+4
+            const uint32_t hi = o == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, o + 1);            // bytes o+5..o+8
+            hv[o] = __builtin_amdgcn_udot4(hi, kB, __builtin_amdgcn_udot4(lo, kA, 0u, false), false);
+        }
+        uint2 pk;
+        pk.x = hv[0] | (hv[1] << 16);
+        pk.y = hv[2] | (hv[3] << 16);
+        *reinterpret_cast<uint2 *>(&hs[r * BL_HP + cg * 4]) = pk;
     }
     __syncthreads();
     const int r = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 4;
     const int y = ty0 + r;
     if (y < h && tx0 + c0 < pitch) {
+        uint32_t acc[4] = {32768u, 32768u, 32768u, 32768u};
+        const uint32_t kv[7] = {k0, k1, k2, k3, k2, k1, k0};
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(&hs[(r + j) * BL_HP + c0]);
+            acc[0] += (q.x & 0xffffu) * kv[j];
+            acc[1] += (q.x >> 16) * kv[j];
+            acc[2] += (q.y & 0xffffu) * kv[j];
+            acc[3] += (q.y >> 16) * kv[j];
+        }
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const uint16_t *q = &hs[r * BL_W + c0 + i];
-            const uint32_t acc = k0 * ((uint32_t)q[0] + q[6 * BL_W]) + k1 * ((uint32_t)q[BL_W] + q[5 * BL_W]) +
-                                 k2 * ((uint32_t)q[2 * BL_W] + q[4 * BL_W]) + k3 * (uint32_t)q[3 * BL_W];
-            uint32_t v = (acc + 32768u) >> 16;
+            uint32_t v = acc[i] >> 16;
             v = v > 255u ? 255u : v;
             out |= v << (8 * i);
         }
@@ -138,101 +163,208 @@ struct DescArgs {
     float scale[ORBX_MAX_LEVELS];
 };
 
-// one wave per keypoint slot of a frame
+#define DESC_SLOTS 64  // keypoint slots per workgroup (16 per wave)
+#define PAT_ROWS 31    // orientation patch: rows y-15 .. y+15
+#define PAT_WORDS 9    // 36 staged bytes per row from the aligned word at or below x-15
+#define BLP_ROWS 37    // descriptor window on the blurred level: rows y-18 .. y+18
+#define BLP_WORDS 11   // 44 staged bytes per row from the aligned word at or below x-18
+
+// One workgroup per 64 consecutive output slots of a frame, 16 keypoints per wave.  For each
+// keypoint the wave copies the two windows it needs into LDS with aligned word loads, all issued
+// before the first use (the gathers would otherwise be a chain of dependent global loads), then
+// sums the patch moments, and later samples the 256 tests, from LDS.  In between, one thread per
+// keypoint evaluates cos/sin in double precision (once per keypoint instead of once per lane).
+// The staged rows may run a few bytes past the image width: that stays inside the level slabs,
+// which are allocated with slack behind the last level.
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                   const uint32_t *__restrict__ kept_xy,
                                                   const uint8_t *__restrict__ kept_resp, const int *__restrict__ nkept,
                                                   orbx_keypoint *__restrict__ out_kp, uint8_t *__restrict__ out_desc,
                                                   int *__restrict__ out_n, DescArgs a)
 {
+    __shared__ int s_first[ORBX_MAX_LEVELS + 1];
+    __shared__ float s_angle[DESC_SLOTS], s_ca[DESC_SLOTS], s_sa[DESC_SLOTS];
+    __shared__ uint32_t s_win[4][BLP_ROWS * BLP_WORDS];  // per wave; the smaller patch reuses it
+    __shared__ uint32_t s_xy[DESC_SLOTS];                // level coordinates of the block's keypoints
+    __shared__ int s_lvl[DESC_SLOTS], s_ki[DESC_SLOTS];  // their level and index into the kept arrays
     const int f = blockIdx.y;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    // level-major concatenation: find the level of this slot
-    int lvl = 0, first = 0, total = 0;
-    {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
         int acc = 0;
-        bool found = false;
         for (int l = 0; l < a.nlevels; l++) {
-            const int c = nkept[f * a.nlevels + l];
-            if (!found && slot < acc + c) {
-                lvl = l, first = acc, found = true;
-            }
-            acc += c;
+            s_first[l] = acc;
+            acc += nkept[f * a.nlevels + l];
         }
-        total = acc;
-        if (blockIdx.x == 0 && threadIdx.x == 0)
-            out_n[f] = total;
-        if (!found)
-            return;
+        s_first[a.nlevels] = acc;
+        if (blockIdx.x == 0)
+            out_n[f] = acc;
     }
-    const int i = slot - first;
-    const uint32_t xy = kept_xy[(size_t)f * a.kp_per_frame + a.kp_base[lvl] + i];
-    const int x = xy & 0xffff, y = xy >> 16;
-    const int pitch = a.pitch[lvl];
-    const uint8_t *img = pyr + (size_t)f * a.slab + a.off[lvl] + (size_t)y * pitch + x;
-    const uint8_t *bl = blur + (size_t)f * a.slab + a.off[lvl] + (size_t)y * pitch + x;
+    __syncthreads();
+    const int total = s_first[a.nlevels];
+    const int base = blockIdx.x * DESC_SLOTS;
+    if (base >= total)
+        return;
+    uint32_t *win = s_win[wv];
+    const uint8_t *winb = reinterpret_cast<const uint8_t *>(win);
+    // all keypoints of the block are located with one round of loads, so that the window fetches
+    // below depend on LDS only
+    if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
+        const int slot = base + threadIdx.x;
+        int lvl = 0;
+        while (slot >= s_first[lvl + 1])
+            lvl++;
+        const int ki = a.kp_base[lvl] + (slot - s_first[lvl]);
+        s_lvl[threadIdx.x] = lvl;
+        s_ki[threadIdx.x] = ki;
+        s_xy[threadIdx.x] = kept_xy[(size_t)f * a.kp_per_frame + ki];
+    }
+    __syncthreads();
+    auto locate = [&](int slot, int &lvl, int &x, int &y, size_t &ki) {
+        const int ls = slot - base;
+        lvl = s_lvl[ls];
+        ki = (size_t)f * a.kp_per_frame + s_ki[ls];
+        const uint32_t xy = s_xy[ls];
+        x = xy & 0xffff, y = xy >> 16;
+    };
+    const int nmine = min(16, total - (base + wv * 16));  // keypoints of this wave (may be <= 0)
 
     // ---- IC_Angle: lanes 0..30 take columns u=-15..15 of rows v = 0,2,4.., lanes 32..62 of rows 1,3,5.. ----
-    int m10 = 0, m01 = 0;
-    {
+    // The window of keypoint i+1 is fetched into registers while keypoint i is summed.
+    uint32_t tmp[7];
+    int ox_next = 0;
+    auto fetch_patch = [&](int slot) {
+        int lvl, x, y;
+        size_t ki;
+        locate(slot, lvl, x, y, ki);
+        const int pitch = a.pitch[lvl];
+        const int xa = (x - 15) & ~3;
+        ox_next = (x - 15) - xa;
+        const uint8_t *src = pyr + (size_t)f * a.slab + a.off[lvl] + (size_t)(y - 15) * pitch + xa;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int idx = lane + 64 * j;
+            const int r = idx / PAT_WORDS, c = idx % PAT_WORDS;
+            tmp[j] = idx < PAT_ROWS * PAT_WORDS ? *reinterpret_cast<const uint32_t *>(src + (size_t)r * pitch + 4 * c)
+                                                : 0u;
+        }
+    };
+    if (nmine > 0)
+        fetch_patch(base + wv * 16);
+    for (int i = 0; i < nmine; i++) {
+        const int ls = wv * 16 + i;
+        const int ox = ox_next;
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+            if (lane + 64 * j < PAT_ROWS * PAT_WORDS)
+                win[lane + 64 * j] = tmp[j];
+        if (i + 1 < nmine)
+            fetch_patch(base + ls + 1);
+        __builtin_amdgcn_wave_barrier();
+        int m10 = 0, m01 = 0;
         const int u = (lane & 31) - 15;
         const int half = lane >> 5;
         if ((lane & 31) < 31) {
-            for (int vv = half; vv <= 15; vv += 2) {
-                if (abs(u) <= c_umax[vv]) {
+            const uint8_t *ctr = winb + 15 * (PAT_WORDS * 4) + ox + 15 + u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int vv = half + 2 * k;
+                const bool in = abs(u) <= c_umax[vv];
+                const int vp = ctr[vv * (PAT_WORDS * 4)], vm = ctr[-vv * (PAT_WORDS * 4)];
+                if (in) {
                     if (vv == 0)
-                        m10 += u * img[u];
+                        m10 += u * vp;
                     else {
-                        const int vp = img[u + vv * pitch], vm = img[u - vv * pitch];
                         m10 += u * (vp + vm);
                         m01 += vv * (vp - vm);
                     }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             m10 += __shfl_xor(m10, d, 64);
             m01 += __shfl_xor(m01, d, 64);
         }
+        if (lane == 0)
+            s_angle[ls] = fast_atan2_deg((float)m01, (float)m10);
     }
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    __syncthreads();
+    if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        const float rad = __fmul_rn(s_angle[threadIdx.x], factorPI);
+        s_ca[threadIdx.x] = (float)cos((double)rad);
+        s_sa[threadIdx.x] = (float)sin((double)rad);
+    }
+    __syncthreads();
 
     // ---- steered BRIEF: lane L evaluates tests L, L+64, L+128, L+192; a ballot yields 64 descriptor bits ----
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    const float rad = __fmul_rn(angle, factorPI);
-    const float ca = (float)cos((double)rad), sa = (float)sin((double)rad);
-    unsigned long long bits[4];
+    float px0[4], py0[4], px1[4], py1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int tst = lane + 64 * j;
-        const char4 p = *reinterpret_cast<const char4 *>(&c_pattern[tst * 4]);
-        const float x0 = (float)p.x, y0 = (float)p.y, x1 = (float)p.z, y1 = (float)p.w;
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
-        const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
-        const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-        const int t0 = bl[r0 * pitch + q0], t1 = bl[r1 * pitch + q1];
-        bits[j] = __ballot(t0 < t1);
+        const char4 p = *reinterpret_cast<const char4 *>(&c_pattern[(lane + 64 * j) * 4]);
+        px0[j] = (float)p.x, py0[j] = (float)p.y, px1[j] = (float)p.z, py1[j] = (float)p.w;
     }
-    const size_t o = (size_t)f * a.out_cap + slot;
-    if (lane < 4)
-        *reinterpret_cast<unsigned long long *>(out_desc + o * 32 + lane * 8) =
-            lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-    if (lane == 0) {
-        orbx_keypoint kp;
-        kp.x = (float)x, kp.y = (float)y;
-        if (lvl != 0) {
-            kp.x = __fmul_rn(kp.x, a.scale[lvl]);
-            kp.y = __fmul_rn(kp.y, a.scale[lvl]);
+    int nx = 0, ny = 0, nlvl = 0;
+    size_t nki = 0;
+    auto fetch_window = [&](int slot) {
+        locate(slot, nlvl, nx, ny, nki);
+        const int pitch = a.pitch[nlvl];
+        const int xa = (nx - 18) & ~3;
+        ox_next = (nx - 18) - xa;
+        const uint8_t *src = blur + (size_t)f * a.slab + a.off[nlvl] + (size_t)(ny - 18) * pitch + xa;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            const int idx = lane + 64 * j;
+            const int r = idx / BLP_WORDS, c = idx % BLP_WORDS;
+            tmp[j] = idx < BLP_ROWS * BLP_WORDS ? *reinterpret_cast<const uint32_t *>(src + (size_t)r * pitch + 4 * c)
+                                                : 0u;
         }
-        kp.size = (float)a.patch_size[lvl];
-        kp.angle = angle;
-        kp.response = (float)kept_resp[(size_t)f * a.kp_per_frame + a.kp_base[lvl] + i];
-        kp.octave = lvl;
-        kp.class_id = -1;
-        out_kp[o] = kp;
+    };
+    if (nmine > 0)
+        fetch_window(base + wv * 16);
+    for (int i = 0; i < nmine; i++) {
+        const int ls = wv * 16 + i, slot = base + ls;
+        const int ox = ox_next, x = nx, y = ny, lvl = nlvl;
+        const size_t ki = nki;
+        __builtin_amdgcn_wave_barrier();  // the previous keypoint's samples are read before this overwrite
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (lane + 64 * j < BLP_ROWS * BLP_WORDS)
+                win[lane + 64 * j] = tmp[j];
+        if (i + 1 < nmine)
+            fetch_window(slot + 1);
+        __builtin_amdgcn_wave_barrier();
+        const float ca = s_ca[ls], sa = s_sa[ls];
+        const uint8_t *ctr = winb + 18 * (BLP_WORDS * 4) + ox + 18;
+        unsigned long long bits[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[j], sa), __fmul_rn(py0[j], ca)));
+            const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[j], ca), __fmul_rn(py0[j], sa)));
+            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[j], sa), __fmul_rn(py1[j], ca)));
+            const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[j], ca), __fmul_rn(py1[j], sa)));
+            const int t0 = ctr[r0 * (BLP_WORDS * 4) + q0], t1 = ctr[r1 * (BLP_WORDS * 4) + q1];
+            bits[j] = __ballot(t0 < t1);
+        }
+        const size_t o = (size_t)f * a.out_cap + slot;
+        if (lane < 4)
+            *reinterpret_cast<unsigned long long *>(out_desc + o * 32 + lane * 8) =
+                lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+        if (lane == 0) {
+            orbx_keypoint kp;
+            kp.x = (float)x, kp.y = (float)y;
+            if (lvl != 0) {
+                kp.x = __fmul_rn(kp.x, a.scale[lvl]);
+                kp.y = __fmul_rn(kp.y, a.scale[lvl]);
+            }
+            kp.size = (float)a.patch_size[lvl];
+            kp.angle = s_angle[ls];
+            kp.response = (float)kept_resp[ki];
+            kp.octave = lvl;
+            kp.class_id = -1;
+            out_kp[o] = kp;
+        }
     }
 }
 
@@ -245,7 +377,7 @@ hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStre
         a.pitch[l] = L.pitch, a.off[l] = L.off, a.kp_base[l] = L.kp_base, a.patch_size[l] = L.patch_size;
         a.scale[l] = L.scale;
     }
-    dim3 grid((g.out_cap + 3) / 4, g.batch);
+    dim3 grid((g.out_cap + DESC_SLOTS - 1) / DESC_SLOTS, g.batch);
     k_describe<<<grid, 256, 0, s>>>(b.pyr, b.blur, b.kept_xy, b.kept_resp, b.nkept, b.out_kp, b.out_desc, b.out_n, a);
     return hipGetLastError();
 }

@@ -5,335 +5,367 @@
 // not depend on the threshold t:  A(p) = max over the 16 arcs of 9 contiguous ring pixels of
 // min(v - ring) and of min(ring - v).  p is a corner at t  <=>  A(p) > t, and it survives the
 // non-maximum suppression of its cell  <=>  A(p) > A(q) for the 8 neighbours q that lie in the same
-// cell's detect region (pixels 3 or more inside the cell window).  The detect regions of the cells
-// tile [19, w-19) x [19, h-19) exactly, so one map per level serves both thresholds:
-//   k_fast_nms   : A for every pixel, kept only where it is a strict local maximum inside its cell
-//   k_cell_count : per cell, survivors above iniThFAST, else above minThFAST (the fallback of :874-878)
-//   k_cell_scan  : exclusive prefix over the cells of a level (cells row-major)
-//   k_cell_emit  : ordered compaction (cell-major, row-major inside a cell), as the reference appends
+// cell's detect region (pixels 3 or more inside the cell window); neighbours with A(q) <= t lose
+// against A(p) > t anyway.  The detect regions of the cells tile [19, w-19) x [19, h-19) exactly.
+// So one pass per level serves both thresholds: every strict per-cell local maximum with
+// A > min(iniThFAST, minThFAST) is appended to the level's candidate list, and a per-cell counter records how many
+// of them exceed iniThFAST.  The consumer keeps a candidate iff A > iniThFAST, or its cell has no
+// such candidate (the fallback of :874-878).  Candidates are appended in arbitrary order; each
+// carries an order key (cell-major, then row-major inside the cell), the order in which the
+// reference appends them.
+//
+// Work per 64x64 tile:  stage the image tile (+4 px) in LDS; test every pixel of the tile (+1 px
+// ring) against the four compass points, two pixels per packed 16-bit operation (a 9-arc contains at
+// least one pixel of each antipodal pair); queue the few that pass; compute A only for those, both
+// polarities at once with packed 16-bit min/max; suppress non-maxima; append.
+#include <cstdlib>
+
 #include "orbx_internal.h"
 
-#define A_PITCH 68  // LDS row pitch of the score tile (66 used)
+#define IMG_W (ORBX_FAST_W + 8)  // 72 staged columns: tx0-4 .. tx0+67
+#define IMG_H (ORBX_FAST_H + 8)  // 72 staged rows:    ty0-4 .. ty0+67
+#define SC_W (ORBX_FAST_W + 2)   // 66: tile plus a one-pixel ring (staged columns 3..68)
+#define SC_H (ORBX_FAST_H + 2)   // 66: staged rows 3..68
+#define GRP_W (IMG_W / 4)        // 18 four-pixel groups per staged row
 
-__device__ __forceinline__ int min9_max(const int (&d)[16])
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
 {
-    // max over the 16 circular windows of length 9 of the window minimum, by doubling:
-    // m2[k] = min(d[k],d[k+1]), m4[k] = min(m2[k],m2[k+2]), m8[k] = min(m4[k],m4[k+4]), m9[k] = min(m8[k], d[k+8])
-    int m2[16], m4[16], best = -256;
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m2[k] = min(d[k], d[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        m4[k] = min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int m8 = min(m4[k], m4[(k + 4) & 15]);
-        best = max(best, min(m8, d[(k + 8) & 15]));
-    }
-    return best;
+    const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
+{
+    const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    const i16x2 r = __builtin_bit_cast(i16x2, a) - __builtin_bit_cast(i16x2, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+// bytes (b0,b1,b2,b3) of w -> (b0 | b1<<16) and (b2 | b3<<16)
+__device__ __forceinline__ uint32_t widen_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); }
+__device__ __forceinline__ uint32_t widen_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }
+
+// Compass test of two pixels at once (u16 halves).  A 9-arc holds at least one pixel of each
+// antipodal pair, so a corner at threshold t needs  max(min(r0,r8), min(r4,r12)) < v-t  (dark arc)
+// or  min(max(r0,r8), max(r4,r12)) > v+t  (bright arc).  Returns sign bits (0x8000 per half) set
+// where the test passes; tt = t | t<<16.
+__device__ __forceinline__ uint32_t compass2(uint32_t v, uint32_t r0, uint32_t r8, uint32_t r4, uint32_t r12,
+                                             uint32_t tt)
+{
+    const uint32_t dk = pk_max(pk_min(r0, r8), pk_min(r4, r12));
+    const uint32_t br = pk_min(pk_max(r0, r8), pk_max(r4, r12));
+    // dark: dk + t - v < 0 ; bright: v + t - br < 0   (all values < 512: no 16-bit overflow)
+    const uint32_t a = pk_sub(dk + tt, v);
+    const uint32_t b = pk_sub(v + tt, br);
+    return (a | b) & 0x80008000u;
 }
 
-__device__ __forceinline__ int fast_arc_score(const uint8_t *t, int p /* pitch of the LDS image tile */)
+// t points at the centre byte of the staged tile.  Ring bytes are widened to p | (255-p)<<16:
+// max over a 9-arc of the low halves = brightest ring pixel of the arc, of the high halves =
+// 255 - darkest.  Both polarities at once:
+//   dark   (ring < v):  max_arcs min(v - ring) = v - min_arcs max_9(ring)
+//   bright (ring > v):  max_arcs min(ring - v) = (255 - min_arcs max_9(255 - ring)) - v
+__device__ __forceinline__ int fast_arc_score(const uint8_t *t)
 {
-    const int v = t[0];
-    int d[16];
-    d[0] = v - t[3 * p];
-    d[1] = v - t[3 * p + 1];
-    d[2] = v - t[2 * p + 2];
-    d[3] = v - t[p + 3];
-    d[4] = v - t[3];
-    d[5] = v - t[-p + 3];
-    d[6] = v - t[-2 * p + 2];
-    d[7] = v - t[-3 * p + 1];
-    d[8] = v - t[-3 * p];
-    d[9] = v - t[-3 * p - 1];
-    d[10] = v - t[-2 * p - 2];
-    d[11] = v - t[-p - 3];
-    d[12] = v - t[-3];
-    d[13] = v - t[p - 3];
-    d[14] = v - t[2 * p - 2];
-    d[15] = v - t[3 * p - 1];
-    const int dark = min9_max(d);
-    int e[16];
+    const int p = IMG_W;
+    uint32_t d[16];
+    d[0] = t[3 * p];
+    d[1] = t[3 * p + 1];
+    d[2] = t[2 * p + 2];
+    d[3] = t[p + 3];
+    d[4] = t[3];
+    d[5] = t[-p + 3];
+    d[6] = t[-2 * p + 2];
+    d[7] = t[-3 * p + 1];
+    d[8] = t[-3 * p];
+    d[9] = t[-3 * p - 1];
+    d[10] = t[-2 * p - 2];
+    d[11] = t[-p - 3];
+    d[12] = t[-3];
+    d[13] = t[p - 3];
+    d[14] = t[2 * p - 2];
+    d[15] = t[3 * p - 1];
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        e[k] = -d[k];
-    const int bright = min9_max(e);
+        d[k] = (d[k] * 0x10001u) ^ 0x00ff0000u;
+    uint32_t m2[16], m4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m2[k] = pk_max(d[k], d[(k + 1) & 15]);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        m4[k] = pk_max(m2[k], m2[(k + 2) & 15]);
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t m8 = pk_max(m4[k], m4[(k + 4) & 15]);
+        best = pk_min(best, pk_max(m8, d[(k + 8) & 15]));
+    }
+    const int v = t[0];
+    const int dark = v - (int)(best & 0xffff);
+    const int bright = 255 - (int)(best >> 16) - v;
     return max(dark, bright);
 }
 
 struct FastArgs {
-    int nlevels;
-    int slab;
+    int nlevels, slab, cells_per_frame, cand_per_frame, tiles_per_frame;
+    int t_low, t_ini;  // min(iniThFAST, minThFAST) and iniThFAST, clamped to [1,255]
+    int dbg_stop;      // timing experiments only: 1..4 = leave after staging / compass / score / before the append
     int tile_base[ORBX_MAX_LEVELS + 1];
     int tiles_x[ORBX_MAX_LEVELS];
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
-    int wcell[ORBX_MAX_LEVELS], hcell[ORBX_MAX_LEVELS];
+    int wcell[ORBX_MAX_LEVELS], hcell[ORBX_MAX_LEVELS], ncols[ORBX_MAX_LEVELS], cell_base[ORBX_MAX_LEVELS];
+    int cand_base[ORBX_MAX_LEVELS], cand_cap[ORBX_MAX_LEVELS];
 };
 
-#define IMG_W (ORBX_FT_W + 8)  // 72
-#define IMG_H (ORBX_FT_H + 8)  // 24
-
-__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ nms,
-                                                  FastArgs a)
+__global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, int *__restrict__ tile_cnt,
+                                              uint2 *__restrict__ tile_list, uint8_t *__restrict__ cell_flag,
+                                              FastArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t img[IMG_H * IMG_W];
-    __shared__ uint8_t sc[(ORBX_FT_H + 2) * A_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t img[IMG_H * IMG_W];  // staged pixels
+    __shared__ __attribute__((aligned(16))) uint8_t sc[IMG_H * IMG_W];   // A where it exceeds t_low, else 0 (staged coordinates)
+    __shared__ uint16_t queue[SC_H * SC_W];  // pixels that passed the compass test: staged row<<7 | staged column
+    __shared__ int qn, sn;
 
     const int f = blockIdx.y;
     int lvl = 0;
     while (lvl + 1 < a.nlevels && (int)blockIdx.x >= a.tile_base[lvl + 1])
         lvl++;
     const int t = blockIdx.x - a.tile_base[lvl];
-    const int tx0 = (t % a.tiles_x[lvl]) * ORBX_FT_W;
-    const int ty0 = (t / a.tiles_x[lvl]) * ORBX_FT_H;
+    const int tx0 = (t % a.tiles_x[lvl]) * ORBX_FAST_W;
+    const int ty0 = (t / a.tiles_x[lvl]) * ORBX_FAST_H;
     const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
+    const int wc = a.wcell[lvl], hc = a.hcell[lvl];
+    const int x_lo = ORBX_CELL_ORG, x_hi = w - ORBX_CELL_ORG, y_lo = ORBX_CELL_ORG, y_hi = h - ORBX_CELL_ORG;
+    // tiles that hold no detectable pixel, and levels without a cell grid, produce nothing
+    int *my_cnt = tile_cnt + (size_t)f * a.tiles_per_frame + blockIdx.x;
+    if (wc == 0 || tx0 + ORBX_FAST_W <= x_lo || tx0 >= x_hi || ty0 + ORBX_FAST_H <= y_lo || ty0 >= y_hi) {
+        if (threadIdx.x == 0)
+            *my_cnt = 0;
+        return;
+    }
     const uint8_t *src = pyr + (size_t)f * a.slab + a.off[lvl];
-    uint8_t *dst = nms + (size_t)f * a.slab + a.off[lvl];
 
-    // stage rows ty0-4 .. ty0+19, columns tx0-4 .. tx0+67 (word aligned: tx0 is a multiple of 64)
-    for (int i = threadIdx.x; i < IMG_H * (IMG_W / 4); i += 256) {
-        const int r = i / (IMG_W / 4), c4 = i % (IMG_W / 4);
+    if (threadIdx.x == 0)
+        qn = 0, sn = 0;
+    // stage rows ty0-4 .. ty0+67, columns tx0-4 .. tx0+67 (word aligned: tx0 is a multiple of 64)
+    for (int i = threadIdx.x; i < IMG_H * GRP_W; i += 256) {
+        const int r = i / GRP_W, c4 = i % GRP_W;
         const int y = ty0 - 4 + r, x = tx0 - 4 + c4 * 4;
         uint32_t v = 0;
         if (y >= 0 && y < h && x >= 0 && x < pitch)
             v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * pitch + x);
-        *reinterpret_cast<uint32_t *>(&img[r * IMG_W + c4 * 4]) = v;
+        reinterpret_cast<uint32_t *>(img)[i] = v;
     }
     __syncthreads();
+    if (a.dbg_stop == 1)
+        return;
 
-    // A for the tile plus a one-pixel ring (66 x 18); zero outside [19, w-19) x [19, h-19)
-    const int x_lo = ORBX_CELL_ORG, x_hi = w - ORBX_CELL_ORG, y_lo = ORBX_CELL_ORG, y_hi = h - ORBX_CELL_ORG;
-    for (int i = threadIdx.x; i < (ORBX_FT_H + 2) * (ORBX_FT_W + 2); i += 256) {
-        const int r = i / (ORBX_FT_W + 2), c = i % (ORBX_FT_W + 2);
-        const int y = ty0 - 1 + r, x = tx0 - 1 + c;
-        int A = 0;
-        if (x >= x_lo && x < x_hi && y >= y_lo && y < y_hi) {
-            A = fast_arc_score(&img[(r + 3) * IMG_W + (c + 3)], IMG_W);
-            A = A < 0 ? 0 : A;
-        }
-        sc[r * A_PITCH + c] = (uint8_t)A;
-    }
-    __syncthreads();
-
-    // strict local maximum among the neighbours that share the pixel's cell
-    const int wc = a.wcell[lvl], hc = a.hcell[lvl];
-    const int r = threadIdx.x >> 4;        // 0..15
-    const int c0 = (threadIdx.x & 15) * 4; // 0..60
-    const int y = ty0 + r;
-    uint32_t out = 0;
-    if (y < h) {
+    // ---- compass test, four pixels per thread, on staged rows 3..68 (tile rows -1..64) ----
+    const int tm = a.t_low;
+    const uint32_t tt = (uint32_t)tm * 0x10001u;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = threadIdx.x - lane; i0 < SC_H * GRP_W; i0 += 256) {  // whole waves only: shuffles below
+        const int i = i0 + lane;
+        uint32_t pass = 0;  // bit o: pixel o of the group passed
+        int r = 0, g = 0;
+        if (i < SC_H * GRP_W) {
+            r = i / GRP_W + 3, g = i % GRP_W;  // staged row, group
+            reinterpret_cast<uint32_t *>(sc)[r * GRP_W + g] = 0u;
+            const int y = ty0 - 4 + r, xg = tx0 - 4 + 4 * g;
+            // the groups left and right of the tile hold one needed pixel each; the image border none
+            if (y >= y_lo && y < y_hi && xg + 3 >= x_lo && xg < x_hi) {
+                const uint32_t *wrow = reinterpret_cast<const uint32_t *>(img) + r * GRP_W + g;
+                const uint32_t vw = wrow[0], upw = wrow[-3 * GRP_W], dnw = wrow[3 * GRP_W];
+                const uint32_t lw = g > 0 ? wrow[-1] : 0u, rw = g < GRP_W - 1 ? wrow[1] : 0u;
+                const uint32_t r4w = __builtin_amdgcn_alignbyte(rw, vw, 3);   // pixels x+3
+                const uint32_t r12w = __builtin_amdgcn_alignbyte(vw, lw, 1);  // pixels x-3
+                const uint32_t m0 = compass2(widen_lo(vw), widen_lo(dnw), widen_lo(upw), widen_lo(r4w),
+                                             widen_lo(r12w), tt);
+                const uint32_t m1 = compass2(widen_hi(vw), widen_hi(dnw), widen_hi(upw), widen_hi(r4w),
+                                             widen_hi(r12w), tt);
+                pass = ((m0 >> 15) & 1u) | ((m0 >> 30) & 2u) | ((m1 >> 13) & 4u) | ((m1 >> 28) & 8u);
+                // keep only pixels inside the score region and the detectable range
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int c = c0 + i, x = tx0 + c;
-            const uint8_t *p = &sc[(r + 1) * A_PITCH + (c + 1)];
-            const int A = p[0];
-            if (A > 0 && wc > 0) {
-                // A > 0 implies x in [19, w-19), y in [19, h-19)
-                const int cx0 = ORBX_CELL_ORG + ((x - ORBX_CELL_ORG) / wc) * wc;
-                const int cy0 = ORBX_CELL_ORG + ((y - ORBX_CELL_ORG) / hc) * hc;
-                const bool l = x - 1 >= cx0, rr = (x + 1 < cx0 + wc) && (x + 1 < x_hi);
-                const bool u = y - 1 >= cy0, dn = (y + 1 < cy0 + hc) && (y + 1 < y_hi);
-                int m = 0;
-                if (l) m = max(m, (int)p[-1]);
-                if (rr) m = max(m, (int)p[1]);
-                if (u) {
-                    m = max(m, (int)p[-A_PITCH]);
-                    if (l) m = max(m, (int)p[-A_PITCH - 1]);
-                    if (rr) m = max(m, (int)p[-A_PITCH + 1]);
+                for (int o = 0; o < 4; o++) {
+                    const int x = xg + o;
+                    if (x < x_lo || x >= x_hi || 4 * g + o < 3 || 4 * g + o > 3 + SC_W - 1)
+                        pass &= ~(1u << o);
                 }
-                if (dn) {
-                    m = max(m, (int)p[A_PITCH]);
-                    if (l) m = max(m, (int)p[A_PITCH - 1]);
-                    if (rr) m = max(m, (int)p[A_PITCH + 1]);
-                }
-                if (A > m)
-                    out |= (uint32_t)A << (8 * i);
             }
         }
-        if (tx0 + c0 < pitch)
-            *reinterpret_cast<uint32_t *>(dst + (size_t)y * pitch + tx0 + c0) = out;
+        // ordered compaction: one LDS atomic per wave and round
+        const int cnt = __popc(pass);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int tmp = __shfl_up(incl, d, 64);
+            if (lane >= d)
+                incl += tmp;
+        }
+        const int wave_total = __shfl(incl, 63, 64);
+        int wbase = 0;
+        if (wave_total > 0) {
+            if (lane == 63)
+                wbase = atomicAdd(&qn, wave_total);
+            wbase = __shfl(wbase, 63, 64);
+            int k = wbase + incl - cnt;
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+                if (pass & (1u << o))
+                    queue[k++] = (uint16_t)((r << 7) | (4 * g + o));
+        }
+    }
+    __syncthreads();
+    if (a.dbg_stop == 2)
+        return;
+
+    // ---- full score for the queued pixels ----
+    const int nq = qn;
+    for (int qi = threadIdx.x; qi < nq; qi += 256) {
+        const int e = queue[qi];
+        const int r = e >> 7, c = e & 127;  // staged row / column
+        const int A = fast_arc_score(&img[r * IMG_W + c]);
+        if (A > tm)
+            sc[r * IMG_W + c] = (uint8_t)A;
+    }
+    __syncthreads();
+    if (a.dbg_stop == 3)
+        return;
+
+    // ---- non-maximum suppression inside the pixel's cell, on the tile proper ----
+    // Survivors go to the tile's own list (no global atomics); a later pass concatenates the lists.
+    uint2 *my_list = tile_list + ((size_t)f * a.tiles_per_frame + blockIdx.x) * ORBX_TILE_CAP;
+    uint8_t *flags = cell_flag + (size_t)f * a.cells_per_frame + a.cell_base[lvl];
+    for (int qi = threadIdx.x; qi < nq; qi += 256) {
+        const int e = queue[qi];
+        const int r = e >> 7, c = e & 127;
+        if (r < 4 || r >= 4 + ORBX_FAST_H || c < 4 || c >= 4 + ORBX_FAST_W)
+            continue;  // ring pixel: belongs to a neighbouring tile
+        const uint8_t *p = &sc[r * IMG_W + c];
+        const int A = p[0];
+        if (A == 0)
+            continue;
+        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
+        const int cj = (x - ORBX_CELL_ORG) / wc, ci = (y - ORBX_CELL_ORG) / hc;
+        const int cx0 = ORBX_CELL_ORG + cj * wc, cy0 = ORBX_CELL_ORG + ci * hc;
+        const bool l = x - 1 >= cx0, rr = x + 1 < cx0 + wc;
+        const bool u = y - 1 >= cy0, dn = y + 1 < cy0 + hc;
+        int m = 0;
+        if (l) m = max(m, (int)p[-1]);
+        if (rr) m = max(m, (int)p[1]);
+        if (u) {
+            m = max(m, (int)p[-IMG_W]);
+            if (l) m = max(m, (int)p[-IMG_W - 1]);
+            if (rr) m = max(m, (int)p[-IMG_W + 1]);
+        }
+        if (dn) {
+            m = max(m, (int)p[IMG_W]);
+            if (l) m = max(m, (int)p[IMG_W - 1]);
+            if (rr) m = max(m, (int)p[IMG_W + 1]);
+        }
+        if (A > m && a.dbg_stop != 4) {
+            const int cell = ci * a.ncols[lvl] + cj;
+            const int k = atomicAdd(&sn, 1);  // LDS; at most ORBX_TILE_CAP strict per-cell maxima fit a tile
+            // x | y<<12 relative to (16,16) | cornerScore<<24 ; order key of the reference's candidate list
+            my_list[k] = make_uint2((uint32_t)(x - ORBX_BORDER) | ((uint32_t)(y - ORBX_BORDER) << 12) |
+                                        ((uint32_t)(A - 1) << 24),
+                                    ((uint32_t)cell << 12) | ((uint32_t)(y - cy0) << 6) | (uint32_t)(x - cx0));
+            if (A > a.t_ini)
+                flags[cell] = 1;  // the cell has a corner above iniThFAST
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *my_cnt = sn;
+}
+
+// Concatenates the tile lists of every (frame, level) into the level's candidate arrays.
+// One workgroup per tile: its offset is the sum of the counts of the level's earlier tiles.
+__global__ __launch_bounds__(64) void k_gather(const int *__restrict__ tile_cnt, const uint2 *__restrict__ tile_list,
+                                               int *__restrict__ ncand, uint32_t *__restrict__ cand_xy,
+                                               uint8_t *__restrict__ cand_resp, uint32_t *__restrict__ cand_key,
+                                               int *__restrict__ status, FastArgs a)
+{
+    const int f = blockIdx.y;
+    int lvl = 0;
+    while (lvl + 1 < a.nlevels && (int)blockIdx.x >= a.tile_base[lvl + 1])
+        lvl++;
+    const int first = a.tile_base[lvl], ntiles = a.tile_base[lvl + 1] - first;
+    const int me = blockIdx.x - first;
+    const int *cnt = tile_cnt + (size_t)f * a.tiles_per_frame + first;
+    const int lane = threadIdx.x;
+    int before = 0, all = 0;
+    for (int i = lane; i < ntiles; i += 64) {
+        const int c = cnt[i];
+        all += c;
+        before += i < me ? c : 0;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += __shfl_xor(before, d, 64);
+        all += __shfl_xor(all, d, 64);
+    }
+    const int cap = a.cand_cap[lvl];
+    if (me == 0) {
+        if (lane == 0) {
+            ncand[f * a.nlevels + lvl] = all;
+            if (all > cap)
+                atomicMax(&status[ORBX_ST_CAND_OVERFLOW], all);
+        }
+    }
+    const int mine = cnt[me];
+    const uint2 *src = tile_list + ((size_t)f * a.tiles_per_frame + blockIdx.x) * ORBX_TILE_CAP;
+    const size_t cb = (size_t)f * a.cand_per_frame + a.cand_base[lvl];
+    for (int j = lane; j < mine; j += 64) {
+        const int k = before + j;
+        if (k < cap) {
+            const uint2 v = src[j];
+            cand_xy[cb + k] = (v.x & 0xfffu) | (((v.x >> 12) & 0xfffu) << 16);
+            cand_resp[cb + k] = (uint8_t)(v.x >> 24);
+            cand_key[cb + k] = v.y;
+        }
     }
 }
 
-hipError_t orbx_launch_fast_nms(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
+hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
 {
     FastArgs a;
     a.nlevels = g.nlevels;
     a.slab = g.slab;
-    for (int l = 0; l < g.nlevels; l++) {
-        const OrbxLevel &L = g.lv[l];
-        a.tile_base[l] = L.tile_base;
-        a.tiles_x[l] = L.tiles_x;
-        a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
-        a.wcell[l] = L.wcell, a.hcell[l] = L.hcell;
-    }
-    a.tile_base[g.nlevels] = g.tiles_per_frame;
-    dim3 grid(g.tiles_per_frame, g.batch);
-    k_fast_nms<<<grid, 256, 0, s>>>(b.pyr, b.nms, a);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------- cells
-
-struct CellArgs {
-    int nlevels, slab, cells_per_frame, cand_per_frame;
-    int ini_th, min_th;
-    int cell_base[ORBX_MAX_LEVELS + 1];
-    int ncols[ORBX_MAX_LEVELS];
-    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
-    int wcell[ORBX_MAX_LEVELS], hcell[ORBX_MAX_LEVELS];
-    int cand_base[ORBX_MAX_LEVELS], cand_cap[ORBX_MAX_LEVELS];
-};
-
-struct CellRect {
-    int lvl, x0, x1, y0, y1;
-};
-
-__device__ __forceinline__ CellRect cell_rect(const CellArgs &a, int cell)
-{
-    CellRect r;
-    int lvl = 0;
-    while (lvl + 1 < a.nlevels && cell >= a.cell_base[lvl + 1])
-        lvl++;
-    const int c = cell - a.cell_base[lvl];
-    const int j = c % a.ncols[lvl], i = c / a.ncols[lvl];
-    r.lvl = lvl;
-    r.x0 = ORBX_CELL_ORG + j * a.wcell[lvl];
-    r.y0 = ORBX_CELL_ORG + i * a.hcell[lvl];
-    r.x1 = min(r.x0 + a.wcell[lvl], a.w[lvl] - ORBX_CELL_ORG);
-    r.y1 = min(r.y0 + a.hcell[lvl], a.h[lvl] - ORBX_CELL_ORG);
-    return r;
-}
-
-#define CELL_INI_FLAG (1 << 30)
-
-// one wave per cell
-__global__ __launch_bounds__(256) void k_cell_count(const uint8_t *__restrict__ nms, int *__restrict__ cell_cnt,
-                                                    CellArgs a)
-{
-    const int f = blockIdx.y;
-    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= a.cells_per_frame)
-        return;
-    const int lane = threadIdx.x & 63;
-    const CellRect r = cell_rect(a, cell);
-    const uint8_t *m = nms + (size_t)f * a.slab + a.off[r.lvl];
-    const int pitch = a.pitch[r.lvl];
-    const int x = r.x0 + lane;
-    const int t_ini = max(a.ini_th, 1), t_min = max(a.min_th, 1);
-    int n_ini = 0, n_min = 0;
-    for (int y = r.y0; y < r.y1; y++) {
-        const int v = (x < r.x1) ? m[(size_t)y * pitch + x] : 0;
-        n_ini += __popcll(__ballot(v > t_ini));
-        n_min += __popcll(__ballot(v > t_min));
-    }
-    if (lane == 0)
-        cell_cnt[(size_t)f * a.cells_per_frame + cell] = n_ini > 0 ? (n_ini | CELL_INI_FLAG) : n_min;
-}
-
-// one workgroup per (level, frame): exclusive prefix over the level's cells
-__global__ __launch_bounds__(256) void k_cell_scan(const int *__restrict__ cell_cnt, int *__restrict__ cell_off,
-                                                   int *__restrict__ ncand, int *__restrict__ status, CellArgs a)
-{
-    __shared__ int part[256];
-    const int lvl = blockIdx.x, f = blockIdx.y;
-    const int base = a.cell_base[lvl], n = a.cell_base[lvl + 1] - base;
-    const int *cnt = cell_cnt + (size_t)f * a.cells_per_frame + base;
-    int *off = cell_off + (size_t)f * a.cells_per_frame + base;
-    const int per = (n + 255) / 256;
-    const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
-    int s = 0;
-    for (int i = lo; i < hi; i++)
-        s += cnt[i] & (CELL_INI_FLAG - 1);
-    part[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 256 partial sums
-    for (int d = 1; d < 256; d <<= 1) {
-        int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = part[threadIdx.x] - s;
-    for (int i = lo; i < hi; i++) {
-        off[i] = run;
-        run += cnt[i] & (CELL_INI_FLAG - 1);
-    }
-    if (threadIdx.x == 255) {
-        const int total = part[255];
-        ncand[f * a.nlevels + lvl] = total;
-        if (total > a.cand_cap[lvl])
-            atomicMax(&status[ORBX_ST_CAND_OVERFLOW], total);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cell_emit(const uint8_t *__restrict__ nms, const int *__restrict__ cell_cnt,
-                                                   const int *__restrict__ cell_off, uint32_t *__restrict__ cand_xy,
-                                                   uint8_t *__restrict__ cand_resp, CellArgs a)
-{
-    const int f = blockIdx.y;
-    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= a.cells_per_frame)
-        return;
-    const int cc = cell_cnt[(size_t)f * a.cells_per_frame + cell];
-    if ((cc & (CELL_INI_FLAG - 1)) == 0)
-        return;
-    const int lane = threadIdx.x & 63;
-    const CellRect r = cell_rect(a, cell);
-    const uint8_t *m = nms + (size_t)f * a.slab + a.off[r.lvl];
-    const int pitch = a.pitch[r.lvl];
-    const int x = r.x0 + lane;
-    const int th = max((cc & CELL_INI_FLAG) ? a.ini_th : a.min_th, 1);
-    int pos = cell_off[(size_t)f * a.cells_per_frame + cell];
-    const int cap = a.cand_cap[r.lvl];
-    uint32_t *oxy = cand_xy + (size_t)f * a.cand_per_frame + a.cand_base[r.lvl];
-    uint8_t *orp = cand_resp + (size_t)f * a.cand_per_frame + a.cand_base[r.lvl];
-    for (int y = r.y0; y < r.y1; y++) {
-        const int v = (x < r.x1) ? m[(size_t)y * pitch + x] : 0;
-        const bool keep = v > th;
-        const unsigned long long mask = __ballot(keep);
-        if (keep) {
-            const int k = pos + __popcll(mask & ((1ull << lane) - 1ull));
-            if (k < cap) {
-                oxy[k] = (uint32_t)(x - ORBX_BORDER) | ((uint32_t)(y - ORBX_BORDER) << 16);
-                orp[k] = (uint8_t)(v - 1);
-            }
-        }
-        pos += __popcll(mask);
-    }
-}
-
-hipError_t orbx_launch_cells(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
-{
-    CellArgs a;
-    a.nlevels = g.nlevels, a.slab = g.slab, a.cells_per_frame = g.cells_per_frame;
+    a.cells_per_frame = g.cells_per_frame;
     a.cand_per_frame = g.cand_per_frame;
-    a.ini_th = min(max(g.ini_th, 0), 255), a.min_th = min(max(g.min_th, 0), 255);
+    a.tiles_per_frame = g.ftiles_per_frame;
+    // cv::FAST clamps the threshold to [0,255]; at t = 0 a corner still needs score A-1 > 0 to beat
+    // its non-corner neighbours, which is A > 1
+    a.t_ini = min(max(g.ini_th, 1), 255);
+    a.t_low = min(a.t_ini, min(max(g.min_th, 1), 255));
+    const char *dbg = getenv("ORBX_DEBUG_FAST_STOP");
+    a.dbg_stop = dbg ? atoi(dbg) : 0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
-        a.cell_base[l] = L.cell_base, a.ncols[l] = L.ncols;
+        a.tile_base[l] = L.ftile_base;
+        a.tiles_x[l] = L.ftiles_x;
         a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
-        a.wcell[l] = L.wcell, a.hcell[l] = L.hcell;
+        a.wcell[l] = L.wcell, a.hcell[l] = L.hcell, a.ncols[l] = L.ncols, a.cell_base[l] = L.cell_base;
         a.cand_base[l] = L.cand_base, a.cand_cap[l] = L.cand_cap;
     }
-    a.cell_base[g.nlevels] = g.cells_per_frame;
-    hipError_t e;
+    a.tile_base[g.nlevels] = g.ftiles_per_frame;
+    hipError_t e = hipSuccess;
     if (g.cells_per_frame > 0) {
-        dim3 grid((g.cells_per_frame + 3) / 4, g.batch);
-        k_cell_count<<<grid, 256, 0, s>>>(b.nms, b.cell_cnt, a);
-        if ((e = hipGetLastError()) != hipSuccess)
+        e = hipMemsetAsync(b.cell_flag, 0, (size_t)g.batch * g.cells_per_frame, s);
+        if (e != hipSuccess)
             return e;
     }
-    k_cell_scan<<<dim3(g.nlevels, g.batch), 256, 0, s>>>(b.cell_cnt, b.cell_off, b.ncand, b.status, a);
+    dim3 grid(g.ftiles_per_frame, g.batch);
+    k_fast<<<grid, 256, 0, s>>>(b.pyr, b.tile_cnt, b.tile_list, b.cell_flag, a);
     if ((e = hipGetLastError()) != hipSuccess)
         return e;
-    if (g.cells_per_frame > 0) {
-        dim3 grid((g.cells_per_frame + 3) / 4, g.batch);
-        k_cell_emit<<<grid, 256, 0, s>>>(b.nms, b.cell_cnt, b.cell_off, b.cand_xy, b.cand_resp, a);
-        if ((e = hipGetLastError()) != hipSuccess)
-            return e;
-    }
-    return hipSuccess;
+    k_gather<<<grid, 64, 0, s>>>(b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.status, a);
+    return hipGetLastError();
 }

@@ -54,31 +54,44 @@ __global__ __launch_bounds__(256) void k_top2_partial(const uint32_t *__restrict
         partial[(size_t)blockIdx.y * nq + qi] = make_uint2(k1, k2);
 }
 
-// one thread per query: fold the chunks in ascending row order
+// One wave per query: the lanes fold a strided subset of the chunks each, then a butterfly merges
+// the 64 partial top-2 pairs.  Keys are distance<<32 | database row, so equal distances resolve to
+// the lower row, as the strict '<' of a single pass over the rows does.
+__device__ __forceinline__ void top2_insert(unsigned long long &k1, unsigned long long &k2, unsigned long long v)
+{
+    const unsigned long long hi = k1 > v ? k1 : v;
+    k1 = k1 < v ? k1 : v;
+    k2 = k2 < hi ? k2 : hi;
+}
+
 __global__ __launch_bounds__(256) void k_top2_merge(const uint2 *__restrict__ partial, int nq, int nchunks,
                                                     int chunk_rows, long long idx_base, int32_t *__restrict__ best,
                                                     uint16_t *__restrict__ d1, uint16_t *__restrict__ d2)
 {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (qi >= nq)
         return;
-    int b1 = 256, b2 = 256;
-    long long bi = -1;
-    for (int c = 0; c < nchunks; c++) {
+    const unsigned long long init = (256ull << 32) | 0xffffffffull;
+    unsigned long long k1 = init, k2 = init;
+    for (int c = lane; c < nchunks; c += 64) {
         const uint2 p = partial[(size_t)c * nq + qi];
-        const int da = p.x >> 16, db = p.y >> 16;
-        if (da < b1) {
-            b2 = b1;
-            b1 = da;
-            bi = (long long)c * chunk_rows + (p.x & 0xffff);
-        } else if (da < b2)
-            b2 = da;
-        if (db < b2)
-            b2 = db;
+        const unsigned long long row0 = (unsigned long long)c * (unsigned long long)chunk_rows;
+        top2_insert(k1, k2, ((unsigned long long)(p.x >> 16) << 32) | (row0 + (p.x & 0xffff)));
+        top2_insert(k1, k2, ((unsigned long long)(p.y >> 16) << 32) | (row0 + (p.y & 0xffff)));
     }
-    best[qi] = bi < 0 ? -1 : (int32_t)(bi + idx_base);
-    d1[qi] = (uint16_t)b1;
-    d2[qi] = (uint16_t)b2;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o1 = __shfl_xor(k1, d, 64), o2 = __shfl_xor(k2, d, 64);
+        top2_insert(k1, k2, o1);
+        k2 = k2 < o2 ? k2 : o2;
+    }
+    if (lane == 0) {
+        const int b1 = (int)(k1 >> 32), b2 = (int)(k2 >> 32);
+        best[qi] = b1 >= 256 ? -1 : (int32_t)((long long)(k1 & 0xffffffffull) + idx_base);
+        d1[qi] = (uint16_t)b1;
+        d2[qi] = (uint16_t)(b2 > 256 ? 256 : b2);
+    }
 }
 
 hipError_t orbx_launch_top2(const uint8_t *d_q, int nq, const uint8_t *d_db, int64_t ndb, int64_t idx_base,
@@ -94,7 +107,7 @@ hipError_t orbx_launch_top2(const uint8_t *d_q, int nq, const uint8_t *d_db, int
         if (e != hipSuccess)
             return e;
     }
-    k_top2_merge<<<qblocks, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_partial), nq, nchunks, chunk_rows,
+    k_top2_merge<<<(nq + 3) / 4, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_partial), nq, nchunks, chunk_rows,
                                          (long long)idx_base, d_best, d_d1, d_d2);
     return hipGetLastError();
 }

@@ -18,22 +18,33 @@
 #include "orbx_internal.h"
 
 struct OctLevel {
-    int cand_base, quota, n_ini, node_cap, kp_base, region_h;
+    int cand_base, cand_cap, cell_base, quota, n_ini, node_cap, kp_base, region_h;
     float hx;
 };
 struct OctArgs {
-    int nlevels, cand_per_frame, kp_per_frame;
+    int nlevels, cand_per_frame, kp_per_frame, cells_per_frame;
+    int t_ini, t_min;  // FAST thresholds clamped to [1,255]
     OctLevel lv[ORBX_MAX_LEVELS];
 };
 
-// arrays of `cap` ints carved from dynamic LDS
+#define OCT_DROPPED 0xffffu  // node value of a candidate that the per-cell threshold fallback discards
+
+// 16 arrays of `cap` ints carved from dynamic LDS; addresses are computed, not stored, so that
+// run-time buffer and quadrant indices cost arithmetic instead of a pointer table in scratch memory
 struct OctLds {
-    int *bx[2], *by[2], *cnt[2], *seq[2];  // node records in list order, double buffered
-    int *cc[4];                            // child key counts of the node at a list position
-    int *prank;                            // processing rank of an expandable node, -1 otherwise
-    int *order;                            // order[r] = list position of the r-th processed node
-    int *nzs;                              // inclusive prefix over r of the non-empty child counts
-    int *spos;                             // new position of a surviving node
+    int *base;
+    int cap;
+    // node records in list order, double buffered (b = 0/1)
+    __device__ __forceinline__ int *bx(int b) const { return base + (4 * b + 0) * cap; }
+    __device__ __forceinline__ int *by(int b) const { return base + (4 * b + 1) * cap; }
+    __device__ __forceinline__ int *cnt(int b) const { return base + (4 * b + 2) * cap; }
+    __device__ __forceinline__ int *seq(int b) const { return base + (4 * b + 3) * cap; }
+    // child key counts of the node at a list position (q = 0..3)
+    __device__ __forceinline__ int *cc(int q) const { return base + (8 + q) * cap; }
+    __device__ __forceinline__ int *prank() const { return base + 12 * cap; }  // processing rank or -1
+    __device__ __forceinline__ int *order() const { return base + 13 * cap; }  // order[r] = list position
+    __device__ __forceinline__ int *nzs() const { return base + 14 * cap; }    // inclusive prefix of non-empty children
+    __device__ __forceinline__ int *spos() const { return base + 15 * cap; }   // new position of a surviving node
 };
 #define OCT_ARRAYS 16
 #define OCT_TAIL_INTS 8  // wave sums of the block scan + the root count, behind the arrays
@@ -77,33 +88,28 @@ __device__ __forceinline__ int quadrant_of(uint32_t xy, int bx, int by)
 }
 
 // Body shared by the batched kernel and the standalone test entry.
-// xy/resp/node: the n candidates of this level (coordinates relative to the detection region's corner).
+// xy/resp/node: the n candidates of this level (coordinates relative to the detection region's corner), in any
+// order.  key (may be null: the index is the key) gives the order in which the reference holds them, cell id in
+// the bits above 12.  cell_ini (may be null: keep all) = per cell, whether any candidate exceeds iniThFAST: a
+// candidate counts iff its score A = resp+1 exceeds t_ini, or its cell has none such and A exceeds t_min
+// (src/ORBextractor.cc:868-878).
 // out_*: kept keypoints in list order (xy as given, plus `add` on both coordinates); out_idx optional.
-__device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__restrict__ resp,
-                            uint16_t *__restrict__ node, int n, int quota, int n_ini, float hx, int region_h,
-                            int cap, int add, uint32_t *__restrict__ out_xy, uint8_t *__restrict__ out_resp,
-                            int *__restrict__ out_idx, int *__restrict__ out_n, int *__restrict__ status)
+// KMAX > 0: every thread keeps its (at most KMAX) candidates in registers, n <= 256*KMAX;
+// KMAX == 0: candidates stay in global memory (`node` is the scratch array), any n.
+template <int KMAX>
+__device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__restrict__ resp,
+                                            const uint32_t *__restrict__ key, const uint8_t *__restrict__ cell_ini,
+                                            int t_ini, int t_min, uint16_t *__restrict__ node, int n, int quota,
+                                            int n_ini, float hx, int region_h, int cap, int add,
+                                            uint32_t *__restrict__ out_xy, uint8_t *__restrict__ out_resp,
+                                            int *__restrict__ out_idx, int *__restrict__ out_n,
+                                            int *__restrict__ status)
 {
     // all LDS lives in the one dynamic array, so its base alignment is not disturbed
     extern __shared__ __attribute__((aligned(16))) int lds[];
     int *wsum = lds + (size_t)OCT_ARRAYS * cap;
     int &sh_size = wsum[4];
-    OctLds L;
-    {
-        int *p = lds;
-        for (int b = 0; b < 2; b++) {
-            L.bx[b] = p, p += cap;
-            L.by[b] = p, p += cap;
-            L.cnt[b] = p, p += cap;
-            L.seq[b] = p, p += cap;
-        }
-        for (int q = 0; q < 4; q++)
-            L.cc[q] = p, p += cap;
-        L.prank = p, p += cap;
-        L.order = p, p += cap;
-        L.nzs = p, p += cap;
-        L.spos = p, p += cap;
-    }
+    const OctLds L{lds, cap};
     const int tid = threadIdx.x;
     if (n <= 0) {
         if (tid == 0)
@@ -112,44 +118,112 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
     }
     const int N = quota;
 
+    // ---- candidate storage ----
+    constexpr int KR = KMAX > 0 ? KMAX : 1;
+    uint32_t rxy[KR];
+    int rnode[KR];
+    unsigned long long rbk[KR];  // response<<32 | ~order key: the maximum is the node's keeper
+    auto for_keys = [&](auto fn) {
+        if constexpr (KMAX > 0) {
+#pragma unroll
+            for (int j = 0; j < KMAX; j++) {
+                const int k = tid + 256 * j;
+                if (k < n)
+                    fn(j, k);
+            }
+        } else {
+            for (int k = tid; k < n; k += 256)
+                fn(0, k);
+        }
+    };
+    auto XY = [&](int j, int k) -> uint32_t {
+        if constexpr (KMAX > 0) return rxy[j];
+        else return xy[k];
+    };
+    auto NODE = [&](int j, int k) -> int {
+        if constexpr (KMAX > 0) return rnode[j];
+        else return node[k];
+    };
+    auto SET_NODE = [&](int j, int k, int v) {
+        if constexpr (KMAX > 0) rnode[j] = v;
+        else node[k] = (uint16_t)v;
+    };
+    auto BK = [&](int j, int k) -> unsigned long long {
+        if constexpr (KMAX > 0) return rbk[j];
+        else
+            return ((unsigned long long)resp[k] << 32) | (unsigned long long)(0xffffffffu - (key ? key[k] : (uint32_t)k));
+    };
+
     // ---- roots (:587-631) ----
     for (int i = tid; i < n_ini; i += 256) {
         const int ulx = (int)(hx * (float)i), urx = (int)(hx * (float)(i + 1));
-        L.bx[1][i] = ulx | (urx << 16);
-        L.by[1][i] = 0 | (region_h << 16);
-        L.cnt[1][i] = 0;
+        L.bx(1)[i] = ulx | (urx << 16);
+        L.by(1)[i] = 0 | (region_h << 16);
+        L.cnt(1)[i] = 0;
+    }
+    if constexpr (KMAX > 0) {
+        // one round of loads brings everything a thread will ever need of its candidates
+        uint8_t rr[KR];
+        uint32_t rk[KR];
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) {
+            const int k = tid + 256 * j;
+            rxy[j] = k < n ? xy[k] : 0u;
+            rr[j] = k < n ? resp[k] : (uint8_t)0;
+            rk[j] = (k < n && key) ? key[k] : (uint32_t)k;
+        }
+#pragma unroll
+        for (int j = 0; j < KMAX; j++)
+            rbk[j] = ((unsigned long long)rr[j] << 32) | (unsigned long long)(0xffffffffu - rk[j]);
     }
     __syncthreads();
-    for (int k = tid; k < n; k += 256) {
-        int r = (int)((float)(xy[k] & 0xffff) / hx);
+    for_keys([&](int j, int k) {
+        if (cell_ini) {
+            const unsigned long long bk = BK(j, k);
+            const int A = (int)(bk >> 32) + 1;
+            const uint32_t ord = 0xffffffffu - (uint32_t)bk;
+            if (!(A > t_ini || (cell_ini[ord >> 12] == 0 && A > t_min))) {
+                SET_NODE(j, k, OCT_DROPPED);
+                return;
+            }
+        }
+        int r = (int)((float)(XY(j, k) & 0xffff) / hx);
         r = r < n_ini ? r : n_ini - 1;
-        node[k] = (uint16_t)r;
-        atomicAdd(&L.cnt[1][r], 1);
-    }
+        SET_NODE(j, k, r);
+        atomicAdd(&L.cnt(1)[r], 1);
+    });
     __syncthreads();
     if (tid == 0) {
         int s = 0;
         for (int i = 0; i < n_ini; i++) {
-            if (L.cnt[1][i] > 0) {
-                L.bx[0][s] = L.bx[1][i], L.by[0][s] = L.by[1][i], L.cnt[0][s] = L.cnt[1][i], L.seq[0][s] = s;
-                L.spos[i] = s++;
+            if (L.cnt(1)[i] > 0) {
+                L.bx(0)[s] = L.bx(1)[i], L.by(0)[s] = L.by(1)[i], L.cnt(0)[s] = L.cnt(1)[i], L.seq(0)[s] = s;
+                L.spos()[i] = s++;
             } else
-                L.spos[i] = 0;
+                L.spos()[i] = 0;
         }
         sh_size = s;
     }
     __syncthreads();
-    for (int k = tid; k < n; k += 256)
-        node[k] = (uint16_t)L.spos[node[k]];
+    for_keys([&](int j, int k) {
+        const int i = NODE(j, k);
+        if (i != OCT_DROPPED)
+            SET_NODE(j, k, L.spos()[i]);
+    });
     int size = sh_size;
+    if (size == 0) {  // every candidate was dropped
+        if (tid == 0)
+            *out_n = 0;
+        return;
+    }
     int cur = 0;
     bool last_kind = false;
     __syncthreads();
 
     for (int round = 0; round < 64; round++) {
         const int prev_size = size;
-        int *bx = L.bx[cur], *by = L.by[cur], *cnt = L.cnt[cur], *seq = L.seq[cur];
-        int *nbx = L.bx[cur ^ 1], *nby = L.by[cur ^ 1], *ncnt = L.cnt[cur ^ 1], *nseq = L.seq[cur ^ 1];
+        int *bx = L.bx(cur), *by = L.by(cur), *cnt = L.cnt(cur), *seq = L.seq(cur);
+        int *nbx = L.bx(cur ^ 1), *nby = L.by(cur ^ 1), *ncnt = L.cnt(cur ^ 1), *nseq = L.seq(cur ^ 1);
         const int per = (size + 255) / 256;
         const int lo = min(tid * per, size), hi = min(lo + per, size);
 
@@ -157,13 +231,13 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
         int my_e = 0;
         for (int i = lo; i < hi; i++) {
             my_e += cnt[i] >= 2;
-            L.cc[0][i] = L.cc[1][i] = L.cc[2][i] = L.cc[3][i] = 0;
+            L.cc(0)[i] = L.cc(1)[i] = L.cc(2)[i] = L.cc(3)[i] = 0;
         }
         int m;
         int ebase = block_excl_scan(my_e, wsum, &m);
         if (!last_kind) {
             for (int i = lo; i < hi; i++)
-                L.prank[i] = cnt[i] >= 2 ? ebase++ : -1;
+                L.prank()[i] = cnt[i] >= 2 ? ebase++ : -1;
         } else {
             for (int i = lo; i < hi; i++) {
                 int rk = -1;
@@ -175,20 +249,20 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
                         rk += (cj >= 2) && (cj > ci || (cj == ci && seq[j] > si));
                     }
                 }
-                L.prank[i] = rk;
+                L.prank()[i] = rk;
             }
         }
         __syncthreads();
         for (int i = lo; i < hi; i++)
-            if (L.prank[i] >= 0)
-                L.order[L.prank[i]] = i;
+            if (L.prank()[i] >= 0)
+                L.order()[L.prank()[i]] = i;
 
         // ---- key counts of the four children (:551-565) ----
-        for (int k = tid; k < n; k += 256) {
-            const int i = node[k];
-            if (cnt[i] >= 2)
-                atomicAdd(&L.cc[quadrant_of(xy[k], bx[i], by[i])][i], 1);
-        }
+        for_keys([&](int j, int k) {
+            const int i = NODE(j, k);
+            if (i != OCT_DROPPED && cnt[i] >= 2)
+                atomicAdd(&L.cc(quadrant_of(XY(j, k), bx[i], by[i]))[i], 1);
+        });
         __syncthreads();
 
         // ---- how many nodes are processed: all, or up to the one that brings the list to N ----
@@ -196,16 +270,16 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
         const int rlo = min(tid * rper, m), rhi = min(rlo + rper, m);
         int my_nz = 0;
         for (int r = rlo; r < rhi; r++) {
-            const int i = L.order[r];
-            my_nz += (L.cc[0][i] > 0) + (L.cc[1][i] > 0) + (L.cc[2][i] > 0) + (L.cc[3][i] > 0);
+            const int i = L.order()[r];
+            my_nz += (L.cc(0)[i] > 0) + (L.cc(1)[i] > 0) + (L.cc(2)[i] > 0) + (L.cc(3)[i] > 0);
         }
         int nz_total;
         int run = block_excl_scan(my_nz, wsum, &nz_total);
         int below = 0;  // processed nodes after which the list is still shorter than N
         for (int r = rlo; r < rhi; r++) {
-            const int i = L.order[r];
-            run += (L.cc[0][i] > 0) + (L.cc[1][i] > 0) + (L.cc[2][i] > 0) + (L.cc[3][i] > 0);
-            L.nzs[r] = run;  // inclusive; list size after r+1 nodes = size + nzs[r] - (r+1)
+            const int i = L.order()[r];
+            run += (L.cc(0)[i] > 0) + (L.cc(1)[i] > 0) + (L.cc(2)[i] > 0) + (L.cc(3)[i] > 0);
+            L.nzs()[r] = run;  // inclusive; list size after r+1 nodes = size + nzs[r] - (r+1)
             below += (size + run - (r + 1)) < N;
         }
         int t = m;
@@ -215,12 +289,12 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
             t = min(t0 + 1, m);
         }
         __syncthreads();
-        const int children = t > 0 ? L.nzs[t - 1] : 0;
+        const int children = t > 0 ? L.nzs()[t - 1] : 0;
 
         // ---- survivors keep their relative order behind the new children ----
         int my_s = 0;
         for (int i = lo; i < hi; i++)
-            my_s += !(L.prank[i] >= 0 && L.prank[i] < t);
+            my_s += !(L.prank()[i] >= 0 && L.prank()[i] < t);
         int nsurv;
         int sbase = block_excl_scan(my_s, wsum, &nsurv);
         const int new_size = children + nsurv;
@@ -233,9 +307,9 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
             return;
         }
         for (int i = lo; i < hi; i++) {
-            if (!(L.prank[i] >= 0 && L.prank[i] < t)) {
+            if (!(L.prank()[i] >= 0 && L.prank()[i] < t)) {
                 const int p = children + sbase++;
-                L.spos[i] = p;
+                L.spos()[i] = p;
                 nbx[p] = bx[i], nby[p] = by[i], ncnt[p] = cnt[i], nseq[p] = seq[i];
             }
         }
@@ -243,13 +317,13 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
         for (int r = rlo; r < rhi; r++) {
             if (r >= t)
                 break;
-            const int i = L.order[r];
+            const int i = L.order()[r];
             const int b_x = bx[i], b_y = by[i];
             const int ulx = b_x & 0xffff, urx = b_x >> 16, uly = b_y & 0xffff, bry = b_y >> 16;
             const int midx = ulx + ((urx - ulx + 1) >> 1), midy = uly + ((bry - uly + 1) >> 1);
-            const int c[4] = {L.cc[0][i], L.cc[1][i], L.cc[2][i], L.cc[3][i]};
+            const int c[4] = {L.cc(0)[i], L.cc(1)[i], L.cc(2)[i], L.cc(3)[i]};
             const int nz = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
-            const int blk = children - L.nzs[r];
+            const int blk = children - L.nzs()[r];
             int before = 0;
             for (int q = 0; q < 4; q++) {
                 if (c[q] == 0)
@@ -258,26 +332,28 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
                 nbx[p] = (q & 1) ? (midx | (urx << 16)) : (ulx | (midx << 16));
                 nby[p] = (q & 2) ? (midy | (bry << 16)) : (uly | (midy << 16));
                 ncnt[p] = c[q];
-                nseq[p] = L.nzs[r] - nz + before;  // creation index inside this round
+                nseq[p] = L.nzs()[r] - nz + before;  // creation index inside this round
                 before++;
             }
         }
         __syncthreads();
         // ---- move the keys to their new node ----
-        for (int k = tid; k < n; k += 256) {
-            const int i = node[k];
-            const int r = L.prank[i];
+        for_keys([&](int j, int k) {
+            const int i = NODE(j, k);
+            if (i == OCT_DROPPED)
+                return;
+            const int r = L.prank()[i];
             if (r >= 0 && r < t) {
-                const int q = quadrant_of(xy[k], bx[i], by[i]);
-                const int c[4] = {L.cc[0][i], L.cc[1][i], L.cc[2][i], L.cc[3][i]};
+                const int q = quadrant_of(XY(j, k), bx[i], by[i]);
+                const int c[4] = {L.cc(0)[i], L.cc(1)[i], L.cc(2)[i], L.cc(3)[i]};
                 const int nz = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
                 int before = 0;
                 for (int qq = 0; qq < q; qq++)
                     before += c[qq] > 0;
-                node[k] = (uint16_t)(children - L.nzs[r] + (nz - 1 - before));
+                SET_NODE(j, k, children - L.nzs()[r] + (nz - 1 - before));
             } else
-                node[k] = (uint16_t)L.spos[i];
-        }
+                SET_NODE(j, k, L.spos()[i]);
+        });
         __syncthreads();
         size = new_size;
         cur ^= 1;
@@ -290,7 +366,7 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
             const int per2 = (size + 255) / 256;
             const int lo2 = min(tid * per2, size), hi2 = min(lo2 + per2, size);
             for (int i = lo2; i < hi2; i++)
-                my_x += L.cnt[cur][i] >= 2;
+                my_x += L.cnt(cur)[i] >= 2;
             int n_expand;
             block_excl_scan(my_x, wsum, &n_expand);
             if (size + 3 * n_expand > N)
@@ -301,48 +377,75 @@ __device__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__re
 
     // ---- best key of every node (:791-810): largest response, first in candidate order ----
     __syncthreads();
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(L.cc[0]);  // cc[0],cc[1] are adjacent
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(L.cc(0));  // cc[0],cc[1] are adjacent
     for (int i = tid; i < size; i += 256)
         best[i] = 0ull;
     __syncthreads();
-    for (int k = tid; k < n; k += 256)
-        atomicMax(&best[node[k]], ((unsigned long long)resp[k] << 32) | (unsigned long long)(0xffffffffu - (uint32_t)k));
+    for_keys([&](int j, int k) {
+        const int i = NODE(j, k);
+        if (i != OCT_DROPPED)
+            atomicMax(&best[i], BK(j, k));
+    });
     __syncthreads();
-    for (int i = tid; i < size; i += 256) {
-        const uint32_t k = 0xffffffffu - (uint32_t)(best[i] & 0xffffffffull);
-        const uint32_t v = xy[k];
-        out_xy[i] = ((v & 0xffff) + add) | (((v >> 16) + add) << 16);
-        out_resp[i] = resp[k];
-        if (out_idx)
-            out_idx[i] = (int)k;
-    }
+    // the winner of a node is the one candidate whose (response, order key) equals the maximum
+    for_keys([&](int j, int k) {
+        const int i = NODE(j, k);
+        if (i == OCT_DROPPED)
+            return;
+        const unsigned long long bk = BK(j, k);
+        if (best[i] == bk) {
+            const uint32_t v = XY(j, k);
+            out_xy[i] = ((v & 0xffff) + add) | (((v >> 16) + add) << 16);
+            out_resp[i] = (uint8_t)(bk >> 32);
+            if (out_idx)
+                out_idx[i] = (int)k;
+        }
+    });
     if (tid == 0)
         *out_n = size;
 }
 
+#define OCT_KMAX 12  // candidates per thread held in registers: levels with up to 3072 candidates
+
+template <typename... Args> __device__ __forceinline__ void octree_dispatch(int n, Args... args)
+{
+    // n is uniform over the workgroup
+    if (n <= 256 * OCT_KMAX)
+        octree_body<OCT_KMAX>(args...);
+    else
+        octree_body<0>(args...);
+}
+
 __global__ __launch_bounds__(256) void k_octree(const uint32_t *__restrict__ cand_xy,
                                                 const uint8_t *__restrict__ cand_resp,
-                                                uint16_t *__restrict__ cand_node, const int *__restrict__ ncand,
-                                                uint32_t *__restrict__ kept_xy, uint8_t *__restrict__ kept_resp,
-                                                int *__restrict__ nkept, int *__restrict__ status, OctArgs a)
+                                                const uint32_t *__restrict__ cand_key,
+                                                const uint8_t *__restrict__ cell_ini, uint16_t *__restrict__ cand_node,
+                                                const int *__restrict__ ncand, uint32_t *__restrict__ kept_xy,
+                                                uint8_t *__restrict__ kept_resp, int *__restrict__ nkept,
+                                                int *__restrict__ status, OctArgs a)
 {
     const int lvl = blockIdx.x, f = blockIdx.y;
     const OctLevel &L = a.lv[lvl];
     const size_t cb = (size_t)f * a.cand_per_frame + L.cand_base;
     const size_t kb = (size_t)f * a.kp_per_frame + L.kp_base;
-    octree_body(cand_xy + cb, cand_resp + cb, cand_node + cb, ncand[f * a.nlevels + lvl], L.quota, L.n_ini, L.hx,
-                L.region_h, L.node_cap, ORBX_BORDER, kept_xy + kb, kept_resp + kb, nullptr,
-                nkept + f * a.nlevels + lvl, status);
+    const int n = min(ncand[f * a.nlevels + lvl], L.cand_cap);  // an overflow is reported by the producer
+    octree_dispatch(n, cand_xy + cb, cand_resp + cb, cand_key + cb,
+                    cell_ini + (size_t)f * a.cells_per_frame + L.cell_base, a.t_ini, a.t_min, cand_node + cb, n,
+                    L.quota, L.n_ini, L.hx, L.region_h, L.node_cap, (int)ORBX_BORDER, kept_xy + kb, kept_resp + kb,
+                    (int *)nullptr, nkept + f * a.nlevels + lvl, status);
 }
 
 hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
 {
     OctArgs a;
     a.nlevels = g.nlevels, a.cand_per_frame = g.cand_per_frame, a.kp_per_frame = g.kp_per_frame;
+    a.cells_per_frame = g.cells_per_frame;
+    a.t_ini = min(max(g.ini_th, 1), 255), a.t_min = min(max(g.min_th, 1), 255);
     int cap = 1;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.lv[l].cand_base = L.cand_base, a.lv[l].quota = L.quota, a.lv[l].n_ini = L.n_ini;
+        a.lv[l].cand_cap = L.cand_cap, a.lv[l].cell_base = L.cell_base;
         a.lv[l].node_cap = L.node_cap, a.lv[l].kp_base = L.kp_base, a.lv[l].region_h = L.max_by - ORBX_BORDER;
         a.lv[l].hx = L.hx;
         cap = L.node_cap > cap ? L.node_cap : cap;
@@ -356,7 +459,8 @@ hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream
             return e;
     }
     k_octree<<<dim3(g.nlevels, g.batch), 256, orbx_octree_lds_bytes(cap), s>>>(
-        b.cand_xy, b.cand_resp, b.cand_node, b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status, a);
+        b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.cand_node, b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status,
+        a);
     return hipGetLastError();
 }
 
@@ -365,7 +469,8 @@ __global__ __launch_bounds__(256) void k_octree_single(const uint32_t *xy, const
                                                        uint32_t *out_xy, uint8_t *out_resp, int *out_idx, int *out_n,
                                                        int *status)
 {
-    octree_body(xy, resp, node, n, quota, n_ini, hx, region_h, cap, 0, out_xy, out_resp, out_idx, out_n, status);
+    octree_dispatch(n, xy, resp, (const uint32_t *)nullptr, (const uint8_t *)nullptr, 0, 0, node, n, quota, n_ini, hx,
+                    region_h, cap, 0, out_xy, out_resp, out_idx, out_n, status);
 }
 
 hipError_t orbx_launch_octree_single(const uint32_t *d_xy, const uint8_t *d_resp, uint16_t *d_node, int n, int region_w,

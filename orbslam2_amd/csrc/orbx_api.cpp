@@ -44,6 +44,8 @@ struct orbx_extractor {
     orbx_params p;
     int device;
     hipStream_t own_stream, stream;
+    hipStream_t aux_stream;        // the blur runs here, beside detection and distribution
+    hipEvent_t ev_pyramid, ev_blur;
     float sf[ORBX_MAX_LEVELS], inv[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], invsig2[ORBX_MAX_LEVELS];
     int quota[ORBX_MAX_LEVELS];
     OrbxGeom cap_geom;  // geometry of max_width x max_height: sizes every buffer
@@ -56,20 +58,20 @@ struct orbx_extractor {
     int xtab_cap, ytab_cap;
     std::vector<int> h_counts, h_nkept;
     bool profiling;
-    std::vector<hipEvent_t> prof_events;  // ORBX_NSTAGES+1 events per profiled batch
+    std::vector<hipEvent_t> prof_events;  // 2*ORBX_NSTAGES events (start, end of each stage) per profiled batch
     size_t prof_used;
 };
 
-static const char *const k_stage_names[ORBX_NSTAGES] = {"ingest", "resize", "fast_nms", "cells",
-                                                        "octree", "blur",   "describe"};
+static const char *const k_stage_names[ORBX_NSTAGES] = {"ingest", "resize", "fast", "octree", "blur", "describe"};
 extern "C" const char *orbx_stage_name(int i) { return i >= 0 && i < ORBX_NSTAGES ? k_stage_names[i] : ""; }
 
-// records the boundary event `idx` of the current profiled batch
-static hipError_t prof_mark(orbx_extractor *ex, int idx)
+// records the start (which = 0) or end (which = 1) event of a stage of the current profiled batch
+// on the stream the stage runs on
+static hipError_t prof_mark(orbx_extractor *ex, int stage, int which, hipStream_t st)
 {
     if (!ex->profiling)
         return hipSuccess;
-    const size_t at = ex->prof_used * (ORBX_NSTAGES + 1) + idx;
+    const size_t at = ex->prof_used * (2 * ORBX_NSTAGES) + 2 * stage + which;
     while (ex->prof_events.size() <= at) {
         hipEvent_t e;
         hipError_t rc = hipEventCreate(&e);
@@ -77,7 +79,7 @@ static hipError_t prof_mark(orbx_extractor *ex, int idx)
             return rc;
         ex->prof_events.push_back(e);
     }
-    return hipEventRecord(ex->prof_events[at], ex->stream);
+    return hipEventRecord(ex->prof_events[at], st);
 }
 
 static inline int round_half_even(float v) { return (int)lrintf(v); }
@@ -123,7 +125,7 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
     g->min_th = ex->p.min_th_fast;
     g->blur_variant = ex->p.blur_variant;
     long long off = 0;
-    int cells = 0, tiles = 0, cand = 0, kps = 0, xt = 0, yt = 0;
+    int cells = 0, tiles = 0, ftiles = 0, cand = 0, kps = 0, xt = 0, yt = 0;
     for (int l = 0; l < g->nlevels; l++) {
         OrbxLevel &L = g->lv[l];
         L.w = round_half_even((float)w * ex->inv[l]);
@@ -153,6 +155,10 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
         L.tiles_y = (L.h + ORBX_FT_H - 1) / ORBX_FT_H;
         L.tile_base = tiles;
         tiles += L.tiles_x * L.tiles_y;
+        L.ftiles_x = (L.w + ORBX_FAST_W - 1) / ORBX_FAST_W;
+        L.ftiles_y = (L.h + ORBX_FAST_H - 1) / ORBX_FAST_H;
+        L.ftile_base = ftiles;
+        ftiles += L.ftiles_x * L.ftiles_y;
         L.cand_base = cand;
         // at most one strict local maximum per 2x2 pixels of a cell
         L.cand_cap = L.ncols > 0 ? align_up((L.w * L.h) / 4 + 4, 4) : 0;
@@ -180,6 +186,7 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
     }
     g->cells_per_frame = cells;
     g->tiles_per_frame = tiles;
+    g->ftiles_per_frame = ftiles;
     g->cand_per_frame = cand;
     g->kp_per_frame = kps;
     g->out_cap = kps;
@@ -251,9 +258,9 @@ template <typename T> static hipError_t dmalloc(T **p, size_t n)
 static void free_buffers(orbx_extractor *ex)
 {
     OrbxBuffers &b = ex->buf;
-    void *ptrs[] = {b.pyr,       b.blur,    b.nms,       b.cell_cnt, b.cell_off, b.ncand,  b.cand_xy, b.cand_resp,
-                    b.cand_node, b.kept_xy, b.kept_resp, b.nkept,    b.out_kp,   b.out_desc, b.out_n,  b.status,
-                    ex->d_xtab,  ex->d_ytab};
+    void *ptrs[] = {b.pyr,       b.blur,    b.cell_flag, b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
+                    b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_desc, b.out_n,   b.status,   ex->d_xtab,
+                    ex->d_ytab};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -269,7 +276,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     *out = nullptr;
     const orbx_params &p = *params;
     if (p.nfeatures < 1 || p.nlevels < 1 || p.nlevels > ORBX_MAX_LEVELS || !(p.scale_factor > 1.0f) ||
-        p.max_width < 1 || p.max_height < 1 || p.max_width > 32767 || p.max_height > 32767 || p.max_batch < 1 ||
+        p.max_width < 1 || p.max_height < 1 || p.max_width > 4096 || p.max_height > 4096 || p.max_batch < 1 ||
         p.blur_variant < 0 || p.blur_variant > 1)
         return ORBX_E_ARG;
     int ndev = 0;
@@ -284,7 +291,8 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->have_batch = false;
     ex->profiling = false;
     ex->prof_used = 0;
-    ex->own_stream = ex->stream = nullptr;
+    ex->own_stream = ex->stream = ex->aux_stream = nullptr;
+    ex->ev_pyramid = ex->ev_blur = nullptr;
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
@@ -302,18 +310,26 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     hipError_t e = hipSetDevice(p.device);
     if (e == hipSuccess)
         e = hipStreamCreateWithFlags(&ex->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipStreamCreateWithFlags(&ex->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&ex->ev_pyramid, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&ex->ev_blur, hipEventDisableTiming);
     ex->stream = ex->own_stream;
     const OrbxGeom &g = ex->cap_geom;
     const size_t B = (size_t)p.max_batch;
     OrbxBuffers &b = ex->buf;
-    if (e == hipSuccess) e = dmalloc(&b.pyr, B * g.slab);
-    if (e == hipSuccess) e = dmalloc(&b.blur, B * g.slab);
-    if (e == hipSuccess) e = dmalloc(&b.nms, B * g.slab);
-    if (e == hipSuccess) e = dmalloc(&b.cell_cnt, B * g.cells_per_frame);
-    if (e == hipSuccess) e = dmalloc(&b.cell_off, B * g.cells_per_frame);
+    // 256 bytes of slack: window copies read whole words that may run past the last row
+    if (e == hipSuccess) e = dmalloc(&b.pyr, B * g.slab + 256);
+    if (e == hipSuccess) e = dmalloc(&b.blur, B * g.slab + 256);
+    if (e == hipSuccess) e = dmalloc(&b.cell_flag, B * g.cells_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.tile_cnt, B * g.ftiles_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.tile_list, B * g.ftiles_per_frame * ORBX_TILE_CAP);
     if (e == hipSuccess) e = dmalloc(&b.ncand, B * g.nlevels);
     if (e == hipSuccess) e = dmalloc(&b.cand_xy, B * g.cand_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.cand_resp, B * g.cand_per_frame);
+    if (e == hipSuccess) e = dmalloc(&b.cand_key, B * g.cand_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.cand_node, B * g.cand_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.kept_xy, B * g.kp_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.kept_resp, B * g.kp_per_frame);
@@ -332,8 +348,10 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         free_buffers(ex);
-        if (ex->own_stream)
-            (void)hipStreamDestroy(ex->own_stream);
+        if (ex->ev_pyramid) (void)hipEventDestroy(ex->ev_pyramid);
+        if (ex->ev_blur) (void)hipEventDestroy(ex->ev_blur);
+        if (ex->aux_stream) (void)hipStreamDestroy(ex->aux_stream);
+        if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
         delete ex;
         return ORBX_E_HIP;
     }
@@ -349,11 +367,14 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *ex)
         return;
     (void)hipSetDevice(ex->device);
     (void)hipStreamSynchronize(ex->stream);
+    (void)hipStreamSynchronize(ex->aux_stream);
     for (hipEvent_t e : ex->prof_events)
         (void)hipEventDestroy(e);
     free_buffers(ex);
-    if (ex->own_stream)
-        (void)hipStreamDestroy(ex->own_stream);
+    if (ex->ev_pyramid) (void)hipEventDestroy(ex->ev_pyramid);
+    if (ex->ev_blur) (void)hipEventDestroy(ex->ev_blur);
+    if (ex->aux_stream) (void)hipStreamDestroy(ex->aux_stream);
+    if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     delete ex;
 }
 
@@ -405,6 +426,7 @@ static int prepare(orbx_extractor *ex, int batch, int w, int h)
             return rc;
         const OrbxGeom &c = ex->cap_geom;
         if (g.slab > c.slab || g.cells_per_frame > c.cells_per_frame || g.cand_per_frame > c.cand_per_frame ||
+            g.ftiles_per_frame > c.ftiles_per_frame ||
             g.kp_per_frame > c.kp_per_frame)
             return ORBX_E_CAPACITY;
         // per-frame strides of the result arrays stay those of the capacity geometry
@@ -433,21 +455,29 @@ static int run_pipeline(orbx_extractor *ex)
     const OrbxGeom &g = ex->geom;
     const OrbxBuffers &b = ex->buf;
     hipStream_t s = ex->stream;
+    hipStream_t s2 = ex->aux_stream;
     HIP_TRY(hipMemsetAsync(b.status, 0, ORBX_ST_COUNT * sizeof(int), s));
-    HIP_TRY(prof_mark(ex, 1));
+    HIP_TRY(prof_mark(ex, 1, 0, s));
     for (int l = 1; l < g.nlevels; l++)
         HIP_TRY(orbx_launch_resize(l, g, b, s));
-    HIP_TRY(prof_mark(ex, 2));
-    HIP_TRY(orbx_launch_fast_nms(g, b, s));
-    HIP_TRY(prof_mark(ex, 3));
-    HIP_TRY(orbx_launch_cells(g, b, s));
-    HIP_TRY(prof_mark(ex, 4));
+    HIP_TRY(prof_mark(ex, 1, 1, s));
+    // the blur only needs the pyramid: it runs on the second stream beside detection and distribution
+    HIP_TRY(hipEventRecord(ex->ev_pyramid, s));
+    HIP_TRY(hipStreamWaitEvent(s2, ex->ev_pyramid, 0));
+    HIP_TRY(prof_mark(ex, 4, 0, s2));
+    HIP_TRY(orbx_launch_blur(g, b, s2));
+    HIP_TRY(prof_mark(ex, 4, 1, s2));
+    HIP_TRY(hipEventRecord(ex->ev_blur, s2));
+    HIP_TRY(prof_mark(ex, 2, 0, s));
+    HIP_TRY(orbx_launch_fast(g, b, s));
+    HIP_TRY(prof_mark(ex, 2, 1, s));
+    HIP_TRY(prof_mark(ex, 3, 0, s));
     HIP_TRY(orbx_launch_octree(g, b, s));
-    HIP_TRY(prof_mark(ex, 5));
-    HIP_TRY(orbx_launch_blur(g, b, s));
-    HIP_TRY(prof_mark(ex, 6));
+    HIP_TRY(prof_mark(ex, 3, 1, s));
+    HIP_TRY(hipStreamWaitEvent(s, ex->ev_blur, 0));
+    HIP_TRY(prof_mark(ex, 5, 0, s));
     HIP_TRY(orbx_launch_describe(g, b, s));
-    HIP_TRY(prof_mark(ex, 7));
+    HIP_TRY(prof_mark(ex, 5, 1, s));
     if (ex->profiling)
         ex->prof_used++;
     ex->have_batch = true;
@@ -462,8 +492,11 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_im
     int rc = prepare(ex, batch, width, height);
     if (rc != ORBX_OK)
         return rc;
-    HIP_TRY(prof_mark(ex, 0));
+    // the previous batch's blur (second stream) reads the pyramid this batch overwrites; the describe
+    // stage of that batch already waited for it, and runs before this ingest on the main stream
+    HIP_TRY(prof_mark(ex, 0, 0, ex->stream));
     HIP_TRY(orbx_launch_ingest(d_images, stride_bytes, frame_stride_bytes, ex->geom, ex->buf, ex->stream));
+    HIP_TRY(prof_mark(ex, 0, 1, ex->stream));
     return run_pipeline(ex);
 }
 
@@ -476,13 +509,14 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
     if (rc != ORBX_OK)
         return rc;
     const OrbxLevel &L0 = ex->geom.lv[0];
-    HIP_TRY(prof_mark(ex, 0));
+    HIP_TRY(prof_mark(ex, 0, 0, ex->stream));
     for (int f = 0; f < batch; f++) {
         if (!images[f])
             return ORBX_E_ARG;
         HIP_TRY(hipMemcpy2DAsync(ex->buf.pyr + (size_t)f * ex->geom.slab + L0.off, L0.pitch, images[f], stride_bytes,
                                  width, height, hipMemcpyHostToDevice, ex->stream));
     }
+    HIP_TRY(prof_mark(ex, 0, 1, ex->stream));
     return run_pipeline(ex);
 }
 
@@ -502,13 +536,14 @@ extern "C" int orbx_extractor_stage_times(orbx_extractor *ex, float *ms_sum, int
         return ORBX_E_ARG;
     HIP_TRY(hipSetDevice(ex->device));
     HIP_TRY(hipStreamSynchronize(ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->aux_stream));
     for (int i = 0; i < ORBX_NSTAGES; i++)
         ms_sum[i] = 0.f;
     for (size_t b = 0; b < ex->prof_used; b++) {
-        const hipEvent_t *ev = &ex->prof_events[b * (ORBX_NSTAGES + 1)];
+        const hipEvent_t *ev = &ex->prof_events[b * (2 * ORBX_NSTAGES)];
         for (int i = 0; i < ORBX_NSTAGES; i++) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
             ms_sum[i] += ms;
         }
     }
@@ -657,10 +692,9 @@ extern "C" int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, int 
 
 extern "C" int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int level, uint8_t *dst, int dst_stride)
 {
-    if (!ex || !dst || (what != 0 && what != 1))
+    if (!ex || !dst || what != 1)
         return ORBX_E_ARG;
-    return download_level(ex, what == 0 ? ex->buf.nms : ex->buf.blur, frame, level, 0, dst, dst_stride, nullptr,
-                          nullptr);
+    return download_level(ex, ex->buf.blur, frame, level, 0, dst, dst_stride, nullptr, nullptr);
 }
 
 extern "C" int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, int *xs, int *ys, int *resp, int cap,
@@ -674,25 +708,45 @@ extern "C" int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, i
         return ORBX_E_ARG;
     HIP_TRY(hipSetDevice(ex->device));
     const OrbxGeom &g = ex->geom;
+    const OrbxLevel &L = g.lv[level];
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, ex->buf.ncand + frame * g.nlevels + level, sizeof(int), hipMemcpyDeviceToHost,
                            ex->stream));
     HIP_TRY(hipStreamSynchronize(ex->stream));
-    *n_out = n;
-    if (n > cap || n > g.lv[level].cand_cap)
+    *n_out = 0;
+    if (n > L.cand_cap)
         return ORBX_E_CAPACITY;
     if (n == 0)
         return ORBX_OK;
-    std::vector<uint32_t> xy(n);
+    std::vector<uint32_t> xy(n), key(n);
     std::vector<uint8_t> rp(n);
-    const size_t o = (size_t)frame * g.cand_per_frame + g.lv[level].cand_base;
+    const int ncell = L.ncols * L.nrows;
+    std::vector<uint8_t> ini(std::max(ncell, 1));
+    const size_t o = (size_t)frame * g.cand_per_frame + L.cand_base;
     HIP_TRY(hipMemcpyAsync(xy.data(), ex->buf.cand_xy + o, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(key.data(), ex->buf.cand_key + o, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, ex->stream));
     HIP_TRY(hipMemcpyAsync(rp.data(), ex->buf.cand_resp + o, (size_t)n, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(ini.data(), ex->buf.cell_flag + (size_t)frame * g.cells_per_frame + L.cell_base,
+                           (size_t)ncell, hipMemcpyDeviceToHost, ex->stream));
     HIP_TRY(hipStreamSynchronize(ex->stream));
+    // the device list is unordered and still holds the candidates that only count when their cell
+    // has none above iniThFAST; apply that rule and sort into the reference's order
+    const int t_ini = std::min(std::max(g.ini_th, 1), 255), t_min = std::min(std::max(g.min_th, 1), 255);
+    std::vector<int> keep;
     for (int i = 0; i < n; i++) {
-        if (xs) xs[i] = (int)(xy[i] & 0xffff);
-        if (ys) ys[i] = (int)(xy[i] >> 16);
-        if (resp) resp[i] = rp[i];
+        const int A = (int)rp[i] + 1;
+        if (A > t_ini || (ini[key[i] >> 12] == 0 && A > t_min))
+            keep.push_back(i);
+    }
+    std::sort(keep.begin(), keep.end(), [&](int a, int b) { return key[a] < key[b]; });
+    *n_out = (int)keep.size();
+    if ((int)keep.size() > cap)
+        return ORBX_E_CAPACITY;
+    for (size_t j = 0; j < keep.size(); j++) {
+        const int i = keep[j];
+        if (xs) xs[j] = (int)(xy[i] & 0xffff);
+        if (ys) ys[j] = (int)(xy[i] >> 16);
+        if (resp) resp[j] = rp[i];
     }
     return ORBX_OK;
 }

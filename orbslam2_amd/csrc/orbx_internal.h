@@ -13,9 +13,15 @@
 #define ORBX_HALF_PATCH 15  // HALF_PATCH_SIZE (src/ORBextractor.cc:73)
 #define ORBX_MAX_ROOTS 64   // quadtree roots per level (round(width/height) of the detection region)
 
-// FAST / NMS tile produced by one workgroup
+// blur tile produced by one workgroup
 #define ORBX_FT_W 64
 #define ORBX_FT_H 16
+// FAST tile produced by one workgroup
+#define ORBX_FAST_W 64
+#define ORBX_FAST_H 64
+// A FAST tile holds at most 34 x 34 strict per-cell local maxima (one per 2x2 pixels of a cell,
+// cells at least 30 px wide): capacity of a tile's candidate list
+#define ORBX_TILE_CAP 1160
 
 struct OrbxLevel {
     int w, h, pitch;  // level size and row pitch (bytes) inside a frame slab
@@ -23,7 +29,8 @@ struct OrbxLevel {
     int max_bx, max_by;  // w-16, h-16
     int ncols, nrows, wcell, hcell;  // cell grid of src/ORBextractor.cc:834-840 (0 when the level is too small)
     int cell_base;   // first cell of the level in the per-frame cell arrays
-    int tiles_x, tiles_y, tile_base;  // FAST tiles of the level in the per-frame tile numbering
+    int tiles_x, tiles_y, tile_base;     // blur tiles of the level in the per-frame tile numbering
+    int ftiles_x, ftiles_y, ftile_base;  // FAST tiles, likewise
     int cand_base, cand_cap;          // segment of the per-frame candidate arrays
     int quota;       // mnFeaturesPerLevel[level]
     int n_ini;       // quadtree roots
@@ -39,7 +46,7 @@ struct OrbxGeom {
     int nlevels, batch;
     int ini_th, min_th;
     int blur_variant;
-    int cells_per_frame, tiles_per_frame, cand_per_frame, kp_per_frame;
+    int cells_per_frame, tiles_per_frame, ftiles_per_frame, cand_per_frame, kp_per_frame;
     int out_cap;  // result rows per frame (== kp_per_frame)
     int slab;     // bytes per frame in the level slabs
     OrbxLevel lv[ORBX_MAX_LEVELS];
@@ -61,12 +68,13 @@ enum { ORBX_ST_CAND_OVERFLOW = 0, ORBX_ST_NODE_OVERFLOW = 1, ORBX_ST_COUNT = 4 }
 struct OrbxBuffers {
     uint8_t *pyr;     // [batch][slab] pyramid levels
     uint8_t *blur;    // [batch][slab] blurred levels
-    uint8_t *nms;     // [batch][slab] per-cell local-maximum score maps
-    int *cell_cnt;    // [batch][cells_per_frame] candidates of each cell (bit 30 set: iniThFAST pass produced them)
-    int *cell_off;    // [batch][cells_per_frame] exclusive prefix inside the level
-    int *ncand;       // [batch][nlevels]
-    uint32_t *cand_xy;   // [batch][cand_per_frame] x | y<<16, relative to (16,16)
-    uint8_t *cand_resp;  // [batch][cand_per_frame]
+    uint8_t *cell_flag;  // [batch][cells_per_frame] 1: the cell has a candidate whose score exceeds iniThFAST
+    int *tile_cnt;       // [batch][ftiles_per_frame] candidates found in each FAST tile
+    uint2 *tile_list;    // [batch][ftiles_per_frame][ORBX_TILE_CAP] x | y<<12 | score<<24 , order key
+    int *ncand;       // [batch][nlevels] candidates appended (before the per-cell threshold decision)
+    uint32_t *cand_xy;   // [batch][cand_per_frame] x | y<<16, relative to (16,16); arbitrary order
+    uint8_t *cand_resp;  // [batch][cand_per_frame] cornerScore = A-1
+    uint32_t *cand_key;  // [batch][cand_per_frame] cell<<12 | row-in-cell<<6 | col-in-cell: the reference's order
     uint16_t *cand_node; // [batch][cand_per_frame] quadtree scratch: node position of each candidate
     uint32_t *kept_xy;   // [batch][kp_per_frame] x | y<<16 in level coordinates, quadtree list order
     uint8_t *kept_resp;  // [batch][kp_per_frame]
@@ -83,8 +91,7 @@ struct OrbxBuffers {
 hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, const OrbxGeom &g, const OrbxBuffers &b,
                               hipStream_t s);
 hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
-hipError_t orbx_launch_fast_nms(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
-hipError_t orbx_launch_cells(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
