@@ -99,7 +99,7 @@ def main():
     if args.batch:
         batch = args.batch
     # synthetic frames, different on every rank, generated on the host and uploaded once
-    stride = w
+    stride = (w + 63) // 64 * 64  # pitch-aligned rows: the extractor reads the frames in place
     host = np.zeros((batch, h, stride), np.uint8)
     for f in range(batch):
         host[f] = orbx.synth_image(0x0B5EED00 + rank * 100003 + f, w, h, 0, stride=stride)

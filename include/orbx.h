@@ -96,7 +96,9 @@ int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width, int height
 /* Throughput form: batch frames already resident in device memory (frame f starts at
  * d_images + f*frame_stride_bytes).  Asynchronous on the handle's stream; results stay in the
  * handle's device buffers until the next batch call.  The images must stay valid and unchanged
- * until the stream has finished the batch. */
+ * until the stream has finished the batch.  When d_images, stride_bytes and frame_stride_bytes are
+ * multiples of 4 the frames are read in place (no copy into the pyramid); orbx_pyramid_level(.., 0, ..)
+ * then reads them again, so they must also stay valid for such a call. */
 int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_images, int batch, int width, int height,
                               int stride_bytes, int64_t frame_stride_bytes);
 /* Same, frames in host memory (uploaded with one async copy per frame). */

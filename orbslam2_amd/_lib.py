@@ -85,6 +85,25 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do not both
+    see the GPU, so when torch is installed its copy is loaded first and liborbx.so (which needs the
+    same soname) binds to it, whichever of the two packages is imported first."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Loads liborbx.so once; raises if it has not been built."""
     global _lib
@@ -92,6 +111,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("liborbx.so not found at %s: build it with `make -C orbslam2_amd/csrc` "
                                "(or __graft_entry__.build())" % LIB_PATH)
+        _preload_shared_hip_runtime()
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

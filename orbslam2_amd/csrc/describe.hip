@@ -2,12 +2,15 @@
 // unblurred level, 256-bit steered BRIEF on the blurred level, scale-back and level-major output
 // (GaussianBlur call src/ORBextractor.cc:1157-1159; IC_Angle :93-124; computeOrbDescriptor :127-169;
 // assembly :1147-1181 of the reference).
+#include <cstdlib>
+
 #include "orbx_internal.h"
 
 // ---------------------------------------------------------------- blur
 
 struct BlurArgs {
     int nlevels, slab, variant;
+    OrbxLevel0 l0;
     int tile_base[ORBX_MAX_LEVELS + 1];
     int tiles_x[ORBX_MAX_LEVELS];
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
@@ -44,7 +47,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int t = blockIdx.x - a.tile_base[lvl];
     const int tx0 = (t % a.tiles_x[lvl]) * BL_W, ty0 = (t / a.tiles_x[lvl]) * BL_H;
     const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
-    const uint8_t *src = pyr + (size_t)f * a.slab + a.off[lvl];
+    const int spitch = lvl == 0 ? a.l0.pitch : pitch;
+    const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
     uint8_t *dst = blur + (size_t)f * a.slab + a.off[lvl];
     const uint32_t k0 = 18, k1 = 34, k2 = a.variant ? 49 : 48, k3 = a.variant ? 55 : 56;
     const uint32_t kA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);  // taps 0..3
@@ -55,13 +59,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         for (int i = threadIdx.x; i < BL_SH * (BL_SW / 4); i += 256) {
             const int r = i / (BL_SW / 4), c4 = i % (BL_SW / 4);
             *reinterpret_cast<uint32_t *>(&img[r * BL_SW + c4 * 4]) =
-                *reinterpret_cast<const uint32_t *>(src + (size_t)(ty0 - 3 + r) * pitch + tx0 - 4 + c4 * 4);
+                *reinterpret_cast<const uint32_t *>(src + (size_t)(ty0 - 3 + r) * spitch + tx0 - 4 + c4 * 4);
         }
     } else {
         for (int i = threadIdx.x; i < BL_SH * BL_SW; i += 256) {
             const int r = i / BL_SW, c = i % BL_SW;
             const int y = reflect101(ty0 - 3 + r, h), x = reflect101(tx0 - 4 + c, w);
-            img[i] = src[(size_t)y * pitch + x];
+            img[i] = src[(size_t)y * spitch + x];
         }
     }
     __syncthreads();
@@ -112,6 +116,7 @@ hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
 {
     BlurArgs a;
     a.nlevels = g.nlevels, a.slab = g.slab, a.variant = g.blur_variant;
+    a.l0 = b.l0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.tile_base[l] = L.tile_base, a.tiles_x[l] = L.tiles_x;
@@ -128,8 +133,8 @@ hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
 #include "brief_pattern.inc"
 };
-// half-width of the circular patch at each |row| (umax, src/ORBextractor.cc:483-505)
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+// half-width of the circular patch at each |row| (umax, src/ORBextractor.cc:483-505):
+// 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3
 
 // cv::fastAtan2 (degrees).  Every operation is rounded separately, as on the host.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
@@ -159,6 +164,8 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 
 struct DescArgs {
     int nlevels, slab, kp_per_frame, out_cap;
+    OrbxLevel0 l0;
+    int dbg_stop;  // timing experiments only: 1..3 = leave after locating / after the moments / after cos,sin
     int pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], kp_base[ORBX_MAX_LEVELS], patch_size[ORBX_MAX_LEVELS];
     float scale[ORBX_MAX_LEVELS];
 };
@@ -187,6 +194,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ uint32_t s_win[4][BLP_ROWS * BLP_WORDS];  // per wave; the smaller patch reuses it
     __shared__ uint32_t s_xy[DESC_SLOTS];                // level coordinates of the block's keypoints
     __shared__ int s_lvl[DESC_SLOTS], s_ki[DESC_SLOTS];  // their level and index into the kept arrays
+    __shared__ int s_pitch[DESC_SLOTS], s_off[DESC_SLOTS];  // row pitch and slab offset of that level (blurred image)
+    __shared__ int s_upitch[DESC_SLOTS];                    // row pitch of the unblurred level
+    __shared__ long long s_usrc[DESC_SLOTS];                // byte offset of the unblurred level from pyr
+    __shared__ float s_scale[DESC_SLOTS], s_size[DESC_SLOTS], s_resp[DESC_SLOTS];
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
@@ -216,15 +227,27 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int ki = a.kp_base[lvl] + (slot - s_first[lvl]);
         s_lvl[threadIdx.x] = lvl;
         s_ki[threadIdx.x] = ki;
+        s_pitch[threadIdx.x] = a.pitch[lvl];
+        s_off[threadIdx.x] = a.off[lvl];
+        s_upitch[threadIdx.x] = lvl == 0 ? a.l0.pitch : a.pitch[lvl];
+        s_usrc[threadIdx.x] = lvl == 0 ? (long long)(a.l0.ptr - pyr) + (long long)f * a.l0.fstride
+                                       : (long long)f * a.slab + a.off[lvl];
+        s_scale[threadIdx.x] = a.scale[lvl];
+        s_size[threadIdx.x] = (float)a.patch_size[lvl];
+        s_resp[threadIdx.x] = (float)kept_resp[(size_t)f * a.kp_per_frame + ki];
         s_xy[threadIdx.x] = kept_xy[(size_t)f * a.kp_per_frame + ki];
     }
     __syncthreads();
-    auto locate = [&](int slot, int &lvl, int &x, int &y, size_t &ki) {
+    if (a.dbg_stop == 1)
+        return;
+    // everything a window fetch needs comes from LDS: no global load sits in front of it
+    auto locate = [&](int slot, int &lvl, int &x, int &y, size_t &ki, int &pitch, int &off) {
         const int ls = slot - base;
         lvl = s_lvl[ls];
         ki = (size_t)f * a.kp_per_frame + s_ki[ls];
         const uint32_t xy = s_xy[ls];
         x = xy & 0xffff, y = xy >> 16;
+        pitch = s_pitch[ls], off = s_off[ls];
     };
     const int nmine = min(16, total - (base + wv * 16));  // keypoints of this wave (may be <= 0)
 
@@ -233,13 +256,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     uint32_t tmp[7];
     int ox_next = 0;
     auto fetch_patch = [&](int slot) {
-        int lvl, x, y;
+        int lvl, x, y, bpitch, off;
         size_t ki;
-        locate(slot, lvl, x, y, ki);
-        const int pitch = a.pitch[lvl];
+        locate(slot, lvl, x, y, ki, bpitch, off);
+        const int pitch = s_upitch[slot - base];
         const int xa = (x - 15) & ~3;
         ox_next = (x - 15) - xa;
-        const uint8_t *src = pyr + (size_t)f * a.slab + a.off[lvl] + (size_t)(y - 15) * pitch + xa;
+        const uint8_t *src = pyr + s_usrc[slot - base] + (size_t)(y - 15) * pitch + xa;
 #pragma unroll
         for (int j = 0; j < 5; j++) {
             const int idx = lane + 64 * j;
@@ -265,10 +288,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const int half = lane >> 5;
         if ((lane & 31) < 31) {
             const uint8_t *ctr = winb + 15 * (PAT_WORDS * 4) + ox + 15 + u;
+            // half-widths of the circular patch for even and odd rows, as immediates
+            constexpr int UM_EVEN[8] = {15, 15, 14, 14, 13, 11, 9, 6};
+            constexpr int UM_ODD[8] = {15, 15, 14, 13, 12, 10, 8, 3};
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int vv = half + 2 * k;
-                const bool in = abs(u) <= c_umax[vv];
+                const bool in = abs(u) <= (half ? UM_ODD[k] : UM_EVEN[k]);
                 const int vp = ctr[vv * (PAT_WORDS * 4)], vm = ctr[-vv * (PAT_WORDS * 4)];
                 if (in) {
                     if (vv == 0)
@@ -290,6 +316,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             s_angle[ls] = fast_atan2_deg((float)m01, (float)m10);
     }
     __syncthreads();
+    if (a.dbg_stop == 2)
+        return;
     if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         const float rad = __fmul_rn(s_angle[threadIdx.x], factorPI);
@@ -297,6 +325,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_sa[threadIdx.x] = (float)sin((double)rad);
     }
     __syncthreads();
+    if (a.dbg_stop == 3)
+        return;
 
     // ---- steered BRIEF: lane L evaluates tests L, L+64, L+128, L+192; a ballot yields 64 descriptor bits ----
     float px0[4], py0[4], px1[4], py1[4];
@@ -308,11 +338,11 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     int nx = 0, ny = 0, nlvl = 0;
     size_t nki = 0;
     auto fetch_window = [&](int slot) {
-        locate(slot, nlvl, nx, ny, nki);
-        const int pitch = a.pitch[nlvl];
+        int pitch, off;
+        locate(slot, nlvl, nx, ny, nki, pitch, off);
         const int xa = (nx - 18) & ~3;
         ox_next = (nx - 18) - xa;
-        const uint8_t *src = blur + (size_t)f * a.slab + a.off[nlvl] + (size_t)(ny - 18) * pitch + xa;
+        const uint8_t *src = blur + (size_t)f * a.slab + off + (size_t)(ny - 18) * pitch + xa;
 #pragma unroll
         for (int j = 0; j < 7; j++) {
             const int idx = lane + 64 * j;
@@ -326,7 +356,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     for (int i = 0; i < nmine; i++) {
         const int ls = wv * 16 + i, slot = base + ls;
         const int ox = ox_next, x = nx, y = ny, lvl = nlvl;
-        const size_t ki = nki;
         __builtin_amdgcn_wave_barrier();  // the previous keypoint's samples are read before this overwrite
 #pragma unroll
         for (int j = 0; j < 7; j++)
@@ -355,12 +384,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             orbx_keypoint kp;
             kp.x = (float)x, kp.y = (float)y;
             if (lvl != 0) {
-                kp.x = __fmul_rn(kp.x, a.scale[lvl]);
-                kp.y = __fmul_rn(kp.y, a.scale[lvl]);
+                kp.x = __fmul_rn(kp.x, s_scale[ls]);
+                kp.y = __fmul_rn(kp.y, s_scale[ls]);
             }
-            kp.size = (float)a.patch_size[lvl];
+            kp.size = s_size[ls];
             kp.angle = s_angle[ls];
-            kp.response = (float)kept_resp[ki];
+            kp.response = s_resp[ls];
             kp.octave = lvl;
             kp.class_id = -1;
             out_kp[o] = kp;
@@ -372,6 +401,9 @@ hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStre
 {
     DescArgs a;
     a.nlevels = g.nlevels, a.slab = g.slab, a.kp_per_frame = g.kp_per_frame, a.out_cap = g.out_cap;
+    a.l0 = b.l0;
+    const char *dbg = getenv("ORBX_DEBUG_DESCRIBE_STOP");
+    a.dbg_stop = dbg ? atoi(dbg) : 0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.pitch[l] = L.pitch, a.off[l] = L.off, a.kp_base[l] = L.kp_base, a.patch_size[l] = L.patch_size;

@@ -114,6 +114,7 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
 
 struct FastArgs {
     int nlevels, slab, cells_per_frame, cand_per_frame, tiles_per_frame;
+    OrbxLevel0 l0;
     int t_low, t_ini;  // min(iniThFAST, minThFAST) and iniThFAST, clamped to [1,255]
     int dbg_stop;      // timing experiments only: 1..4 = leave after staging / compass / score / before the append
     int tile_base[ORBX_MAX_LEVELS + 1];
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     const int t = blockIdx.x - a.tile_base[lvl];
     const int tx0 = (t % a.tiles_x[lvl]) * ORBX_FAST_W;
     const int ty0 = (t / a.tiles_x[lvl]) * ORBX_FAST_H;
-    const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
+    const int w = a.w[lvl], h = a.h[lvl], pitch = lvl == 0 ? a.l0.pitch : a.pitch[lvl];
     const int wc = a.wcell[lvl], hc = a.hcell[lvl];
     const int x_lo = ORBX_CELL_ORG, x_hi = w - ORBX_CELL_ORG, y_lo = ORBX_CELL_ORG, y_hi = h - ORBX_CELL_ORG;
     // tiles that hold no detectable pixel, and levels without a cell grid, produce nothing
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             *my_cnt = 0;
         return;
     }
-    const uint8_t *src = pyr + (size_t)f * a.slab + a.off[lvl];
+    const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
 
     if (threadIdx.x == 0)
         qn = 0, sn = 0;
@@ -338,6 +339,7 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
     FastArgs a;
     a.nlevels = g.nlevels;
     a.slab = g.slab;
+    a.l0 = b.l0;
     a.cells_per_frame = g.cells_per_frame;
     a.cand_per_frame = g.cand_per_frame;
     a.tiles_per_frame = g.ftiles_per_frame;

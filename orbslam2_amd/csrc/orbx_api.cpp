@@ -495,7 +495,15 @@ extern "C" int orbx_extract_batch_device(orbx_extractor *ex, const uint8_t *d_im
     // the previous batch's blur (second stream) reads the pyramid this batch overwrites; the describe
     // stage of that batch already waited for it, and runs before this ingest on the main stream
     HIP_TRY(prof_mark(ex, 0, 0, ex->stream));
-    HIP_TRY(orbx_launch_ingest(d_images, stride_bytes, frame_stride_bytes, ex->geom, ex->buf, ex->stream));
+    const bool in_place = (reinterpret_cast<uintptr_t>(d_images) & 3) == 0 && (stride_bytes & 3) == 0 &&
+                          (frame_stride_bytes & 3) == 0;
+    if (in_place) {
+        // every kernel reads level 0 with aligned word loads: usable where it lies
+        ex->buf.l0 = OrbxLevel0{d_images, (long long)frame_stride_bytes, stride_bytes};
+    } else {
+        HIP_TRY(orbx_launch_ingest(d_images, stride_bytes, frame_stride_bytes, ex->geom, ex->buf, ex->stream));
+        ex->buf.l0 = OrbxLevel0{ex->buf.pyr + ex->geom.lv[0].off, (long long)ex->geom.slab, ex->geom.lv[0].pitch};
+    }
     HIP_TRY(prof_mark(ex, 0, 1, ex->stream));
     return run_pipeline(ex);
 }
@@ -516,6 +524,7 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
         HIP_TRY(hipMemcpy2DAsync(ex->buf.pyr + (size_t)f * ex->geom.slab + L0.off, L0.pitch, images[f], stride_bytes,
                                  width, height, hipMemcpyHostToDevice, ex->stream));
     }
+    ex->buf.l0 = OrbxLevel0{ex->buf.pyr + L0.off, (long long)ex->geom.slab, L0.pitch};
     HIP_TRY(prof_mark(ex, 0, 1, ex->stream));
     return run_pipeline(ex);
 }
@@ -662,8 +671,13 @@ static int download_level(orbx_extractor *ex, const uint8_t *slab_buf, int frame
         return ORBX_E_ARG;
     HIP_TRY(hipSetDevice(ex->device));
     uint8_t *inner = dst + (size_t)border * dst_stride + border;
-    HIP_TRY(hipMemcpy2DAsync(inner, dst_stride, slab_buf + (size_t)frame * ex->geom.slab + L.off, L.pitch, L.w, L.h,
-                             hipMemcpyDeviceToHost, ex->stream));
+    const uint8_t *from = slab_buf + (size_t)frame * ex->geom.slab + L.off;
+    size_t from_pitch = L.pitch;
+    if (level == 0 && slab_buf == ex->buf.pyr) {  // level 0 may still lie in the caller's frames
+        from = ex->buf.l0.ptr + (size_t)frame * ex->buf.l0.fstride;
+        from_pitch = ex->buf.l0.pitch;
+    }
+    HIP_TRY(hipMemcpy2DAsync(inner, dst_stride, from, from_pitch, L.w, L.h, hipMemcpyDeviceToHost, ex->stream));
     HIP_TRY(hipStreamSynchronize(ex->stream));
     if (border > 0) {
         // BORDER_REFLECT_101 frame, as copyMakeBorder leaves it around each level

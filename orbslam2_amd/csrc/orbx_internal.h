@@ -65,8 +65,17 @@ struct OrbxYCoef {
 // device status words written by kernels (index into the status array)
 enum { ORBX_ST_CAND_OVERFLOW = 0, ORBX_ST_NODE_OVERFLOW = 1, ORBX_ST_COUNT = 4 };
 
+// Level 0 of the current batch: the caller's frames when they can be read in place (4-byte aligned
+// rows), else the copy inside the pyramid slabs
+struct OrbxLevel0 {
+    const uint8_t *ptr;  // first pixel of frame 0
+    long long fstride;   // bytes between frames
+    int pitch;           // bytes between rows
+};
+
 struct OrbxBuffers {
-    uint8_t *pyr;     // [batch][slab] pyramid levels
+    OrbxLevel0 l0;
+    uint8_t *pyr;     // [batch][slab] pyramid levels (level 0 only when the frames had to be copied)
     uint8_t *blur;    // [batch][slab] blurred levels
     uint8_t *cell_flag;  // [batch][cells_per_frame] 1: the cell has a candidate whose score exceeds iniThFAST
     int *tile_cnt;       // [batch][ftiles_per_frame] candidates found in each FAST tile

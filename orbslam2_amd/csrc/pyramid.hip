@@ -85,9 +85,9 @@ __device__ __forceinline__ void resize_coef_y(int dy, double scale, int sh, int 
 // Each thread produces 4 adjacent pixels of RS_ROWS destination rows.  When the source bytes of the
 // four pixels fit 12 bytes from an aligned word (any scale factor up to 2), each source row costs
 // three word loads; all loads of a thread are independent.
-__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ pyr_in, uint8_t *__restrict__ pyr_out,
-                                                int slab, int soff, int spitch, int sw, int sh, int doff, int dpitch,
-                                                int dw, int dh, double scale_x, double scale_y)
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_lvl, long long src_fstride,
+                                                uint8_t *__restrict__ pyr_out, int slab, int spitch, int sw, int sh,
+                                                int doff, int dpitch, int dw, int dh, double scale_x, double scale_y)
 {
     const int f = blockIdx.z;
     const int dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ pyr_
 #pragma unroll
     for (int i = 0; i < 4; i++)
         cx[i] = resize_coef_x(min(dx0 + i, dw - 1), scale_x, sw);
-    const uint8_t *sbase = pyr_in + (size_t)f * slab + soff;
+    const uint8_t *sbase = src_lvl + (size_t)f * src_fstride;
     uint8_t *dbase = pyr_out + (size_t)f * slab + doff;
     const int wb = cx[0].s & ~3;                       // aligned byte offset of the first word
     const bool wide = cx[3].s + 1 - wb < 12;           // all needed bytes inside three words
@@ -169,7 +169,9 @@ hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b
     // scale as cv::resize derives it: 1 / (dsize / ssize), in double
     const double scale_x = 1. / ((double)D.w / S.w), scale_y = 1. / ((double)D.h / S.h);
     dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), g.batch);
-    k_resize<<<grid, 256, 0, s>>>(b.pyr, b.pyr, g.slab, S.off, S.pitch, S.w, S.h, D.off, D.pitch, D.w, D.h, scale_x,
-                                  scale_y);
+    const uint8_t *src = level == 1 ? b.l0.ptr : b.pyr + S.off;
+    const long long sfs = level == 1 ? b.l0.fstride : (long long)g.slab;
+    const int spitch = level == 1 ? b.l0.pitch : S.pitch;
+    k_resize<<<grid, 256, 0, s>>>(src, sfs, b.pyr, g.slab, spitch, S.w, S.h, D.off, D.pitch, D.w, D.h, scale_x, scale_y);
     return hipGetLastError();
 }

@@ -166,3 +166,25 @@ def test_octree_random(oracle, seed):
     got = debug_octree(xs, ys, resp, rw, rh, quota)
     want = oracle.distribute_octree(xs, ys, resp, 16, 16 + rw, 16, 16 + rh, quota)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("stride", [1241, 1280, 1244])
+def test_device_batch_in_place_and_copied(oracle, stride):
+    """Frames resident in device memory: rows that are multiples of 4 bytes are read in place,
+    others are copied into the pyramid first; both must give the oracle's result."""
+    import torch
+    w, h, B = 1241, 376, 3
+    host = np.zeros((B, h, stride), np.uint8)
+    for f in range(B):
+        host[f] = orbx.synth_image(SEED + 31 * f, w, h, 0, stride=stride)
+    dev = torch.from_numpy(host).cuda()
+    ex = make_extractor(KITTI, w, h, batch=B)
+    ex.extract_batch_device(dev.data_ptr(), B, w, h, stride, h * stride)
+    n, _ = ex.batch_counts()
+    for f in range(B):
+        kg, dg = ex.batch_download(f)
+        ko, do = oracle_extract(oracle, np.ascontiguousarray(host[f][:, :w]), KITTI)
+        assert n[f] == len(ko)
+        compare_frame(kg, dg, ko, do)
+    lev0 = ex.pyramid_level(1, 0)
+    assert np.array_equal(lev0, host[1][:, :w])
