@@ -88,10 +88,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")  # "gloo" rehearses the N>1 path on one GPU
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import orbslam2_amd as orbx
 
@@ -104,12 +111,22 @@ def main():
     for f in range(batch):
         host[f] = orbx.synth_image(0x0B5EED00 + rank * 100003 + f, w, h, 0, stride=stride)
     frames = torch.from_numpy(host).cuda()
-    stream = torch.cuda.Stream()
-    ex = orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch, device=local_rank)
-    ex.set_stream(stream.cuda_stream)
+    # A stereo pair batch: the left and the right images go through two extractor instances on two
+    # streams, as the reference runs mpORBextractorLeft / mpORBextractorRight in two threads
+    # (src/Frame.cc:79-82).  Each instance takes half of the step's frames.
+    half = batch // 2
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    exs = [orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch - half,
+                             device=local_rank) for _ in range(2)]
+    for e, st in zip(exs, streams):
+        e.set_stream(st.cuda_stream)
+    stream = streams[0]
+    ex = exs[0]
+    eyes = [(frames[:half], half), (frames[half:], batch - half)]
 
     def step():
-        ex.extract_batch_device(frames.data_ptr(), batch, w, h, stride, h * stride)
+        for e, (fr, nb) in zip(exs, eyes):
+            e.extract_batch_device(fr.data_ptr(), nb, w, h, stride, h * stride)
 
     def barrier():
         torch.cuda.synchronize()
@@ -120,23 +137,32 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ex.profile(True)
+    for e in exs:
+        e.profile(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    ex.profile(False)
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    for e in exs:
+        e.profile(False)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    counts, _ = ex.batch_counts()
-    n_kp = float(np.mean(counts))
+    n_kp = float(np.mean(np.concatenate([e.batch_counts()[0] for e in exs])))
+    # per-launch stage times of the left extractor (half a step's frames per launch)
     stage_ms, nprof = ex.stage_times()
     stage_ms = {k: v / max(nprof, 1) for k, v in stage_ms.items()}
+    launch_frames = half
 
+    hamming_sharded = None
+    if world > 1 and not args.no_hamming:
+        try:
+            hamming_sharded = bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev)
+        except Exception as exc:  # the frames/s line must survive a failure of this extra measurement
+            hamming_sharded = {"error": repr(exc)}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -146,7 +172,7 @@ def main():
     fps = frames_total / elapsed
     per_stage_bytes, frame_bytes = algorithmic_bytes(w, h, n_kp)
     dom = max(stage_ms, key=lambda k: stage_ms[k])
-    dom_bytes = per_stage_bytes[dom] * batch
+    dom_bytes = per_stage_bytes[dom] * launch_frames
     dom_s = stage_ms[dom] * 1e-3
     achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -161,15 +187,18 @@ def main():
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "nfeatures": nfeat, "nlevels": 8,
+        "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "extractor_instances": 2, "nfeatures": nfeat, "nlevels": 8,
                    "scale_factor": 1.2, "ini_th_fast": 20, "min_th_fast": 7, "mean_keypoints_per_frame": n_kp,
                    "parallelism": "frame-batch shards, no collective"},
         "roofline": roofline,
-        "stages_ms_per_batch": {k: round(v, 4) for k, v in stage_ms.items()},
+        "stages_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
+        "frames_per_launch": launch_frames,
     }
 
     if world == 1 and not args.no_hamming:
         out["hamming"] = bench_hamming(orbx, torch, stream)
+    if world > 1 and hamming_sharded is not None:
+        out["hamming"] = hamming_sharded
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host, w, nfeat, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
@@ -215,6 +244,52 @@ def bench_hamming(orbx, torch, stream):
                          "peak": round(VALU_LANE_OPS_PER_S / 1e12, 3), "unit": "Tlane-op/s",
                          "frac": round(rate / peak_pairs, 4),
                          "frac_of_measured_issue_rate": round(rate * OPS_PER_PAIR / VALU_LANE_OPS_MEASURED, 4)}}
+
+
+def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
+    """2000 queries x 1M rows, rows sharded over the ranks, per-shard top-2 exchanged with one all-gather
+    (RCCL) and merged on every rank."""
+    from orbslam2_amd.sharded import ShardedMatcher, shard_bounds
+    nq, ndb = 2000, 1_000_000
+    lo, hi = shard_bounds(ndb, rank, world)
+    full = orbx.synth_descriptors(1, ndb)
+    step = ndb // nq
+    q = full[::step][:nq].copy()
+    q[:, 0] ^= 0x5A
+    db = torch.from_numpy(full[lo:hi].copy()).cuda()
+    dq = torch.from_numpy(q).cuda()
+    del full
+    best = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    m = orbx.ORBmatcher(0.75)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def local(qq, base):
+        m.match_top2_device(qq.data_ptr(), nq, db.data_ptr(), hi - lo, base, best.data_ptr(), d1.data_ptr(),
+                            d2.data_ptr())
+        return best, d1, d2
+
+    sm = ShardedMatcher(local, rank, world, device=coll_dev)
+    for _ in range(3):
+        res = sm.match(dq, lo)
+    torch.cuda.synchronize()
+    dist.barrier()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = sm.match(dq, lo)
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    sec = float(dt.item()) / reps
+    ok = bool((res[0] == np.arange(nq) * step).all())
+    rate = nq * ndb / sec
+    return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
+            "shards": world, "exchange": "all_gather of 12 B per query and rank, host merge", "self_check": ok,
+            "roofline": {"bound": "valu-int32", "achieved": round(rate * OPS_PER_PAIR / 1e12 / world, 3),
+                         "peak": round(VALU_LANE_OPS_PER_S / 1e12, 3), "unit": "Tlane-op/s per GPU",
+                         "frac": round(rate / world / (VALU_LANE_OPS_PER_S / OPS_PER_PAIR), 4)}}
 
 
 def cpu_baseline(host_frames, w, nfeat, budget_s):

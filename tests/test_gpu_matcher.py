@@ -123,3 +123,30 @@ def test_search_for_initialization_vs_oracle(oracle):
         assert np.array_equal(m12, om12)
         assert np.array_equal(prev_g, prev_o)
         assert n > 50
+
+
+def test_golden_top2_and_device_sharded_path():
+    import os
+    import torch
+    from orbslam2_amd.sharded import ShardedMatcher
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "top2_64x5000.npz"))
+    db = orbx.synth_descriptors(11, 5000)
+    q = db[::78][:64].copy()
+    q[:, 3] ^= 0x3C
+    m = orbx.ORBmatcher(0.75)
+    best, d1, d2 = m.match_top2(q, db)
+    assert np.array_equal(best, g["best"]) and np.array_equal(d1, g["d1"]) and np.array_equal(d2, g["d2"])
+    # device-resident form through the sharded wrapper (world size 1: no exchange, same merge code)
+    ddb, dq = torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda()
+    tb = torch.zeros(64, dtype=torch.int32, device="cuda")
+    t1 = torch.zeros(64, dtype=torch.int16, device="cuda")
+    t2 = torch.zeros(64, dtype=torch.int16, device="cuda")
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def local(qq, base):
+        m.match_top2_device(qq.data_ptr(), 64, ddb.data_ptr(), 5000, base, tb.data_ptr(), t1.data_ptr(),
+                            t2.data_ptr())
+        return tb, t1, t2
+
+    sb, s1, s2 = ShardedMatcher(local, 0, 1, device="cuda").match(dq, 0)
+    assert np.array_equal(sb, g["best"]) and np.array_equal(s1, g["d1"]) and np.array_equal(s2, g["d2"])

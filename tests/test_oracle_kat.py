@@ -1,0 +1,261 @@
+"""Known-answer tests of the CPU oracle's primitives.  The reference ships no tests or golden vectors
+for this path and its pixel arithmetic lives in OpenCV, which is absent here (parity unpinned), so the
+expected values below were worked out by hand from the published algorithms; each case says how."""
+import numpy as np
+import pytest
+
+
+def test_scale_tables_and_quotas(oracle):
+    # src/ORBextractor.cc:437-475: cumulative float products of (double)1.2f; geometric quotas, remainder last
+    sf, inv, s2, is2 = oracle.scale_tables(1.2, 8)
+    want = np.array([1.0, 1.2, 1.44000006, 1.72800016, 2.07360029, 2.48832035, 2.98598456, 3.58318162], np.float32)
+    assert np.array_equal(sf, want)
+    assert np.array_equal(inv, np.float32(1.0) / sf) and np.array_equal(s2, sf * sf)
+    assert list(oracle.features_per_level(1000, 1.2, 8)) == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert list(oracle.features_per_level(2000, 1.2, 8)) == [434, 362, 302, 251, 209, 175, 145, 122]
+    assert list(oracle.features_per_level(4000, 1.2, 8)) == [869, 724, 603, 503, 419, 349, 291, 242]
+    assert list(oracle.features_per_level(1200, 1.2, 8)) == [261, 217, 181, 151, 126, 105, 87, 72]
+    assert sum(oracle.features_per_level(1000, 1.2, 8)) == 1000
+
+
+def test_umax(oracle):
+    # src/ORBextractor.cc:483-505: round(sqrt(225 - v^2)) up to v = 11, then mirrored about the diagonal
+    assert list(oracle.umax()) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    # the patch holds 749 pixels
+    assert 31 + 2 * sum(2 * u + 1 for u in oracle.umax()[1:]) == 749
+
+
+def test_resize_constant_and_ramp(oracle):
+    # a constant image stays constant: (b0*(c*2048>>4)>>16) + (b1*(...)>>16) + 2 >> 2 with b0+b1 = 2048
+    src = np.full((40, 60), 200, np.uint8)
+    assert (oracle.resize(src, 50, 33) == 200).all()
+    # 2 -> 1 columns of one row: dx=0 maps to fx = 0.5: (a0,a1) = (1024,1024); values 10 and 30:
+    # H = 10*1024 + 30*1024 = 40960; rows identical (sy clamps): b0 = b1 = 1024 for fy = 0.5
+    # ((1024*(40960>>4))>>16) = 40 ; 40 + 40 + 2 >> 2 = 20
+    src = np.array([[10, 30], [10, 30]], np.uint8)
+    assert oracle.resize(src, 1, 1)[0, 0] == 20
+    # identity size keeps the image
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(17, 23), dtype=np.uint8)
+    assert np.array_equal(oracle.resize(img, 23, 17), img)
+
+
+def test_resize_matches_float_bilinear_within_one(oracle):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, size=(48, 64), dtype=np.uint8)
+    dw, dh = 53, 40
+    got = oracle.resize(img, dw, dh).astype(np.float64)
+    sx = (np.arange(dw) + 0.5) * (64 / dw) - 0.5
+    sy = (np.arange(dh) + 0.5) * (48 / dh) - 0.5
+    x0 = np.clip(np.floor(sx).astype(int), 0, 62)
+    y0 = np.clip(np.floor(sy).astype(int), 0, 46)
+    fx = np.clip(sx - x0, 0, 1)
+    fy = np.clip(sy - y0, 0, 1)
+    f = img.astype(np.float64)
+    ref = ((1 - fy)[:, None] * ((1 - fx) * f[y0][:, x0] + fx * f[y0][:, x0 + 1]) +
+           fy[:, None] * ((1 - fx) * f[y0 + 1][:, x0] + fx * f[y0 + 1][:, x0 + 1]))
+    assert np.abs(got - ref).max() <= 1.0
+
+
+def test_gauss_kernel_and_borders(oracle):
+    # impulse response = outer product of the integer kernel, scaled: (k_i*k_j*255 + 32768) >> 16
+    k = np.array([18, 34, 48, 56, 48, 34, 18])
+    img = np.zeros((21, 21), np.uint8)
+    img[10, 10] = 255
+    want = (np.outer(k, k) * 255 + 32768) >> 16
+    assert np.array_equal(oracle.gauss7(img)[7:14, 7:14], want)
+    k1 = np.array([18, 34, 49, 55, 49, 34, 18])
+    want1 = (np.outer(k1, k1) * 255 + 32768) >> 16
+    assert np.array_equal(oracle.gauss7(img, 1)[7:14, 7:14], want1)
+    # constant image: sum 256 keeps it; sum 257 brightens and saturates
+    c = np.full((9, 11), 250, np.uint8)
+    assert (oracle.gauss7(c) == 250).all()
+    assert (oracle.gauss7(c, 1) == min(255, (250 * 257 * 257 + 32768) >> 16)).all()
+    # BORDER_REFLECT_101 equals blurring the reflect-padded image and cropping
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(12, 15), dtype=np.uint8)
+    padded = np.pad(img, 3, mode="reflect")
+    assert np.array_equal(oracle.gauss7(img), oracle.gauss7(padded)[3:-3, 3:-3])
+
+
+def ring(img, x, y):
+    dx = [0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1]
+    dy = [3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3]
+    return [int(img[y + b, x + a]) for a, b in zip(dx, dy)]
+
+
+def test_fast_score_hand_cases(oracle):
+    img = np.full((9, 9), 100, np.uint8)
+    # nine contiguous ring pixels 40 darker: A = 40; ten: still 40; eight: no arc -> A <= 0
+    dx = [0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1]
+    dy = [3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3]
+    for n_dark, want in [(9, 40), (10, 40), (16, 40)]:
+        im = img.copy()
+        for k in range(n_dark):
+            im[4 + dy[(k + 5) % 16], 4 + dx[(k + 5) % 16]] = 60
+        assert oracle.fast_arc_score(im, 4, 4) == want
+    im = img.copy()
+    for k in range(8):
+        im[4 + dy[k], 4 + dx[k]] = 60
+    assert oracle.fast_arc_score(im, 4, 4) <= 0
+    # brighter arc with one weaker pixel: the score is the weakest difference of the best arc
+    im = img.copy()
+    for k in range(9):
+        im[4 + dy[k], 4 + dx[k]] = 180
+    im[4 + dy[4], 4 + dx[4]] = 125
+    assert oracle.fast_arc_score(im, 4, 4) == 25
+
+
+def test_fast_detect_equals_score_definition(oracle):
+    """cv::FAST semantics: corner at t <=> A > t; response = A-1; kept iff strictly greater than the 8
+    neighbours' responses, counting non-corners and pixels outside the inner window as 0."""
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        img = np.full((37, 38), 128, np.uint8)
+        for _ in range(14):
+            x, y = rng.integers(0, 30), rng.integers(0, 30)
+            img[y:y + rng.integers(3, 12), x:x + rng.integers(3, 12)] = rng.integers(0, 256)
+        img = np.clip(img.astype(int) + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8)
+        h, w = img.shape
+        A = np.zeros((h, w), int)
+        for y in range(3, h - 3):
+            for x in range(3, w - 3):
+                A[y, x] = oracle.fast_arc_score(img, x, y)
+        for t in (20, 7, 12):
+            xs, ys, rs = oracle.fast_detect(img, t)
+            got = {(int(a), int(b)): int(c) for a, b, c in zip(xs, ys, rs)}
+            S = np.where(A > t, A - 1, 0)
+            want = {}
+            for y in range(3, h - 3):
+                for x in range(3, w - 3):
+                    if A[y, x] > t:
+                        nb = S[y - 1:y + 2, x - 1:x + 2].copy()
+                        nb[1, 1] = -1
+                        if S[y, x] > nb.max():
+                            want[(x, y)] = S[y, x]
+            assert got == want
+            # row-major order
+            assert list(zip(ys, xs)) == sorted(zip(ys, xs))
+
+
+def test_fast_atan2(oracle):
+    # polynomial approximation of cv::fastAtan2: exact on the axes, within 0.3 degree elsewhere
+    assert oracle.fast_atan2(0.0, 1.0) == 0.0
+    assert oracle.fast_atan2(1.0, 0.0) == 90.0
+    assert oracle.fast_atan2(0.0, -1.0) == 180.0
+    assert oracle.fast_atan2(-1.0, 0.0) == 270.0
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+    rng = np.random.default_rng(4)
+    for _ in range(500):
+        y, x = rng.normal(size=2) * 1000
+        ref = np.degrees(np.arctan2(y, x)) % 360
+        d = abs(oracle.fast_atan2(float(np.float32(y)), float(np.float32(x))) - ref)
+        assert min(d, 360 - d) < 0.3
+
+
+def test_ic_angle_moments(oracle):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(41, 43), dtype=np.uint8)
+    a, m10, m01 = oracle.ic_angle(img, 21, 20)
+    um = oracle.umax()
+    w10 = w01 = 0
+    for v in range(-15, 16):
+        for u in range(-um[abs(v)], um[abs(v)] + 1):
+            w10 += u * int(img[20 + v, 21 + u])
+            w01 += v * int(img[20 + v, 21 + u])
+    assert (m10, m01) == (w10, w01)
+    assert a == oracle.fast_atan2(float(w01), float(w10))
+    # a patch brighter on the right points along +x (0 degrees), brighter below along +y (90 degrees)
+    g = np.tile(np.arange(43, dtype=np.uint8) * 5, (41, 1))
+    assert oracle.ic_angle(g, 21, 20)[0] == 0.0
+    assert oracle.ic_angle(np.ascontiguousarray(g[:41, :41].T), 20, 20)[0] == 90.0
+
+
+def test_brief_bit_layout(oracle):
+    # at angle 0 the sample offsets are the table entries themselves: bit k of byte i compares test 8i+k
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, size=(41, 41), dtype=np.uint8)
+    d = oracle.brief_descriptor(img, 20, 20, 0.0)
+    import re
+    pat = [int(v) for v in re.findall(r"-?\d+", open("orbslam2_amd/csrc/brief_pattern.inc").read().split("\n", 1)[1])]
+    assert len(pat) == 1024
+    for i in range(32):
+        val = 0
+        for k in range(8):
+            x0, y0, x1, y1 = pat[4 * (8 * i + k):4 * (8 * i + k) + 4]
+            val |= int(img[20 + y0, 20 + x0] < img[20 + y1, 20 + x1]) << k
+        assert d[i] == val
+    # rotating by 90 degrees maps (x,y) -> (-y, x): compare with the descriptor of the rotated image at 0 degrees
+    d90 = oracle.brief_descriptor(img, 20, 20, 90.0)
+    rot = np.ascontiguousarray(np.rot90(img, 1))  # rot[r, c] = img[c, 40 - r]
+    # sample (row = x, col = -y) of img equals sample (row = y', col = x') of its clockwise rotation
+    d0r = oracle.brief_descriptor(np.ascontiguousarray(np.rot90(img, -1)), 20, 20, 0.0)
+    assert np.array_equal(d90, d0r) or np.array_equal(d90, oracle.brief_descriptor(rot, 20, 20, 0.0))
+
+
+def test_octree_small_cases(oracle):
+    # fewer candidates than the quota: every candidate is kept (each ends alone in a node)
+    xs = np.array([5, 100, 200, 300, 310], np.int32)
+    ys = np.array([5, 50, 100, 150, 152], np.int32)
+    rs = np.array([10, 20, 30, 40, 50], np.int32)
+    keep = oracle.distribute_octree(xs, ys, rs, 16, 16 + 608, 16, 16 + 448, 100)
+    assert sorted(keep) == [0, 1, 2, 3, 4]
+    # quota 1 with one root: the first split already yields >= 1 nodes; the list holds the children of
+    # the root pushed to the front in the order UL, UR, BL, BR -> BR first.  Keep-best per node.
+    xs = np.array([10, 600, 10, 600, 590], np.int32)
+    ys = np.array([10, 10, 440, 440, 430], np.int32)
+    rs = np.array([9, 8, 7, 6, 30], np.int32)
+    keep = oracle.distribute_octree(xs, ys, rs, 16, 16 + 608, 16, 16 + 448, 1)
+    assert list(keep) == [4, 2, 1, 0]
+    # response ties: the first candidate in list order wins
+    rs = np.array([9, 8, 7, 30, 30], np.int32)
+    assert list(oracle.distribute_octree(xs, ys, rs, 16, 16 + 608, 16, 16 + 448, 1)) == [3, 2, 1, 0]
+
+
+def test_octree_invariants(oracle):
+    rng = np.random.default_rng(7)
+    for quota in (30, 217, 434):
+        pts = set()
+        while len(pts) < 3000:
+            pts.add((int(rng.integers(0, 1209)), int(rng.integers(0, 344))))
+        pts = np.array(sorted(pts, key=lambda t: (t[1], t[0])), np.int32)
+        rs = rng.integers(7, 200, size=len(pts)).astype(np.int32)
+        keep = oracle.distribute_octree(pts[:, 0], pts[:, 1], rs, 16, 16 + 1209, 16, 16 + 344, quota)
+        assert quota <= len(keep) <= quota + 2 or len(keep) <= 16
+        assert len(set(keep.tolist())) == len(keep)
+
+
+def test_descriptor_distance_and_top2(oracle):
+    rng = np.random.default_rng(8)
+    a = rng.integers(0, 256, size=(50, 32), dtype=np.uint8)
+    b = rng.integers(0, 256, size=(70, 32), dtype=np.uint8)
+    for i in range(0, 50, 7):
+        for j in range(0, 70, 11):
+            assert oracle.descriptor_distance(a[i], b[j]) == int(np.unpackbits(a[i] ^ b[j]).sum())
+    best, d1, d2 = oracle.match_top2(a, b)
+    D = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+    assert np.array_equal(best, D.argmin(1))
+    assert np.array_equal(d1, D.min(1))
+    assert np.array_equal(d2, np.sort(D, axis=1)[:, 1])
+
+
+def test_three_maxima_and_ratio(oracle):
+    import ctypes as C
+    def tm(sizes):
+        arr = (C.c_int * 30)(*sizes)
+        i1, i2, i3 = C.c_int(), C.c_int(), C.c_int()
+        oracle.lib().orc_three_maxima(arr, 30, C.byref(i1), C.byref(i2), C.byref(i3))
+        return i1.value, i2.value, i3.value
+    s = [0] * 30
+    s[3], s[7], s[20] = 50, 40, 30
+    assert tm(s) == (3, 7, 20)
+    s[7], s[20] = 4, 6          # 6 >= 10 % of 50 stays second, 4 is dropped
+    assert tm(s) == (3, 20, -1)
+    s[20] = 4                   # second and third below 10 % of the first are both dropped
+    assert tm(s) == (3, -1, -1)
+    s[20] = 5
+    s[7] = 5                    # ties: the earlier bin ranks higher
+    assert tm(s) == (3, 7, 20)
+    assert oracle.lib().orc_ratio_accept(50, 67, 50, 0.75) == 1
+    assert oracle.lib().orc_ratio_accept(51, 200, 50, 0.75) == 0
+    assert oracle.lib().orc_ratio_accept(30, 40, 50, 0.75) == 0   # 30 < 0.75*40 = 30 is false
