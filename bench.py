@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kitti_1241x376_2000kp", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
+    ap.add_argument("--instances", type=int, default=2, help="extractor instances (streams) sharing a step's frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -114,15 +115,16 @@ def main():
     # A stereo pair batch: the left and the right images go through two extractor instances on two
     # streams, as the reference runs mpORBextractorLeft / mpORBextractorRight in two threads
     # (src/Frame.cc:79-82).  Each instance takes half of the step's frames.
-    half = batch // 2
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    exs = [orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch - half,
-                             device=local_rank) for _ in range(2)]
+    ninst = max(1, args.instances)
+    half = (batch + ninst - 1) // ninst
+    streams = [torch.cuda.Stream() for _ in range(ninst)]
+    exs = [orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=half, device=local_rank)
+           for _ in range(ninst)]
     for e, st in zip(exs, streams):
         e.set_stream(st.cuda_stream)
     stream = streams[0]
     ex = exs[0]
-    eyes = [(frames[:half], half), (frames[half:], batch - half)]
+    eyes = [(frames[i * half:(i + 1) * half], min(half, batch - i * half)) for i in range(ninst)]
 
     def step():
         for e, (fr, nb) in zip(exs, eyes):
@@ -187,7 +189,7 @@ def main():
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "extractor_instances": 2, "nfeatures": nfeat, "nlevels": 8,
+        "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "extractor_instances": ninst, "nfeatures": nfeat, "nlevels": 8,
                    "scale_factor": 1.2, "ini_th_fast": 20, "min_th_fast": 7, "mean_keypoints_per_frame": n_kp,
                    "parallelism": "frame-batch shards, no collective"},
         "roofline": roofline,

@@ -6,6 +6,8 @@
 
 #include "orbx_internal.h"
 
+extern "C" __device__ int __ockl_wfred_add_i32(int);  // wave-wide integer sum (device library)
+
 // ---------------------------------------------------------------- blur
 
 struct BlurArgs {
@@ -29,17 +31,26 @@ __device__ __forceinline__ int reflect101(int i, int n)
 #define BL_W 64
 #define BL_H 16
 #define BL_SW (BL_W + 8)   // staged columns tx0-4 .. tx0+67 (word aligned; 3 needed each side)
-#define BL_SH (BL_H + 6)   // staged rows ty0-3 .. ty0+18
-#define BL_HP (BL_W + 4)   // u16 pitch of the horizontal sums (8-byte aligned rows, offset banks)
+#define BL_SH (BL_H + 6)   // staged rows ty0-3 .. ty0+18 (22 rows = 11 row pairs)
+#define BL_PAIRS (BL_SH / 2)
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b), c, false);
+}
 
 // Separable fixed-point filter: horizontal sums fit 16 bits (kernel sum <= 257), the vertical pass
 // rounds with +32768 and shifts by 16; variant 1 (kernel sum 257) saturates to 255.
-// Every thread produces four adjacent pixels: the horizontal pass is two 4-byte dot products per
-// pixel on byte windows cut from three staged words, the vertical pass seven 16-bit multiply-adds.
+// Horizontal pass: a thread takes 4 pixels of two rows; each sum is two 4-byte dot products on byte
+// windows cut from three staged words; the two rows' sums of a column share one LDS word.
+// Vertical pass: a thread takes 4 pixels of one row; its 7 taps are four 2 x u16 dot products on
+// those row-pair words (the pairing decides where the zero tap sits).
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, BlurArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[BL_SH * BL_SW];
-    __shared__ __attribute__((aligned(16))) uint16_t hs[BL_SH * BL_HP];
+    __shared__ __attribute__((aligned(16))) uint32_t hs[BL_PAIRS * BL_W];  // h(row 2p, x) | h(row 2p+1, x) << 16
     const int f = blockIdx.y;
     int lvl = 0;
     while (lvl + 1 < a.nlevels && (int)blockIdx.x >= a.tile_base[lvl + 1])
@@ -56,51 +67,75 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 
     const bool interior = tx0 >= 4 && tx0 + BL_W + 4 <= w && ty0 >= 3 && ty0 + BL_H + 3 <= h;
     if (interior) {
+        int r = threadIdx.x / (BL_SW / 4), c4 = threadIdx.x % (BL_SW / 4);
         for (int i = threadIdx.x; i < BL_SH * (BL_SW / 4); i += 256) {
-            const int r = i / (BL_SW / 4), c4 = i % (BL_SW / 4);
-            *reinterpret_cast<uint32_t *>(&img[r * BL_SW + c4 * 4]) =
+            reinterpret_cast<uint32_t *>(img)[i] =
                 *reinterpret_cast<const uint32_t *>(src + (size_t)(ty0 - 3 + r) * spitch + tx0 - 4 + c4 * 4);
+            r += 14, c4 += 4;  // 256 = 14*18 + 4
+            if (c4 >= BL_SW / 4)
+                c4 -= BL_SW / 4, r++;
         }
     } else {
-        for (int i = threadIdx.x; i < BL_SH * BL_SW; i += 256) {
-            const int r = i / BL_SW, c = i % BL_SW;
-            const int y = reflect101(ty0 - 3 + r, h), x = reflect101(tx0 - 4 + c, w);
-            img[i] = src[(size_t)y * spitch + x];
+        // edge tile: rows and columns outside the image mirror about the border pixel (reflect 101);
+        // words that lie inside the row are still loaded whole
+        for (int i = threadIdx.x; i < BL_SH * (BL_SW / 4); i += 256) {
+            const int r = i / (BL_SW / 4), c4 = i % (BL_SW / 4);
+            const int y = reflect101(ty0 - 3 + r, h), x0 = tx0 - 4 + c4 * 4;
+            const uint8_t *row = src + (size_t)y * spitch;
+            uint32_t v;
+            if (x0 >= 0 && x0 + 3 < w)
+                v = *reinterpret_cast<const uint32_t *>(row + x0);
+            else
+                v = (uint32_t)row[reflect101(x0, w)] | ((uint32_t)row[reflect101(x0 + 1, w)] << 8) |
+                    ((uint32_t)row[reflect101(x0 + 2, w)] << 16) | ((uint32_t)row[reflect101(x0 + 3, w)] << 24);
+            reinterpret_cast<uint32_t *>(img)[i] = v;
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < BL_SH * (BL_W / 4); i += 256) {
-        const int r = i / (BL_W / 4), cg = i % (BL_W / 4);
-        // staged bytes 4cg .. 4cg+11 hold columns x-4 .. x+7 of the group's first pixel x
-        const uint32_t *wp = reinterpret_cast<const uint32_t *>(&img[r * BL_SW + cg * 4]);
-        const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-        uint32_t hv[4];
+    if (threadIdx.x < BL_PAIRS * (BL_W / 4)) {
+        const int p = threadIdx.x >> 4, cg = threadIdx.x & 15;
+        uint32_t hv[2][4];
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            // pixel x+o: taps at staged bytes o+1 .. o+7
-            const uint32_t lo = o == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, o + 1);            // bytes o+1..o+4
-            const uint32_t hi = o == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, o + 1);            // bytes o+5..o+8
-            hv[o] = __builtin_amdgcn_udot4(hi, kB, __builtin_amdgcn_udot4(lo, kA, 0u, false), false);
+        for (int rr = 0; rr < 2; rr++) {
+            // staged bytes 4cg .. 4cg+11 hold columns x-4 .. x+7 of the group's first pixel x
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(&img[(2 * p + rr) * BL_SW + cg * 4]);
+            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                // pixel x+o: taps at staged bytes o+1 .. o+7
+                const uint32_t lo = o == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, o + 1);  // bytes o+1..o+4
+                const uint32_t hi = o == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, o + 1);  // bytes o+5..o+8
+                hv[rr][o] = __builtin_amdgcn_udot4(hi, kB, __builtin_amdgcn_udot4(lo, kA, 0u, false), false);
+            }
         }
-        uint2 pk;
-        pk.x = hv[0] | (hv[1] << 16);
-        pk.y = hv[2] | (hv[3] << 16);
-        *reinterpret_cast<uint2 *>(&hs[r * BL_HP + cg * 4]) = pk;
+        uint4 pk;
+        pk.x = hv[0][0] | (hv[1][0] << 16);
+        pk.y = hv[0][1] | (hv[1][1] << 16);
+        pk.z = hv[0][2] | (hv[1][2] << 16);
+        pk.w = hv[0][3] | (hv[1][3] << 16);
+        *reinterpret_cast<uint4 *>(&hs[p * BL_W + cg * 4]) = pk;
     }
     __syncthreads();
     const int r = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 4;
     const int y = ty0 + r;
     if (y < h && tx0 + c0 < pitch) {
-        uint32_t acc[4] = {32768u, 32768u, 32768u, 32768u};
-        const uint32_t kv[7] = {k0, k1, k2, k3, k2, k1, k0};
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const uint2 q = *reinterpret_cast<const uint2 *>(&hs[(r + j) * BL_HP + c0]);
-            acc[0] += (q.x & 0xffffu) * kv[j];
-            acc[1] += (q.x >> 16) * kv[j];
-            acc[2] += (q.y & 0xffffu) * kv[j];
-            acc[3] += (q.y >> 16) * kv[j];
-        }
+        // output row r sums staged rows r .. r+6 with taps k0 k1 k2 k3 k2 k1 k0
+        const bool odd = r & 1;
+        const int p0 = r >> 1;  // first row pair touched
+        // even r: (k0,k1) (k2,k3) (k2,k1) (k0,0); odd r: (0,k0) (k1,k2) (k3,k2) (k1,k0); low half = even row
+        const uint32_t c01 = odd ? (k0 << 16) : (k0 | (k1 << 16));
+        const uint32_t c23 = odd ? (k1 | (k2 << 16)) : (k2 | (k3 << 16));
+        const uint32_t c45 = odd ? (k3 | (k2 << 16)) : (k2 | (k1 << 16));
+        const uint32_t c67 = odd ? (k1 | (k0 << 16)) : k0;
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 0) * BL_W + c0]);
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 1) * BL_W + c0]);
+        const uint4 q2 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 2) * BL_W + c0]);
+        const uint4 q3 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 3) * BL_W + c0]);
+        uint32_t acc[4];
+        acc[0] = dot2_u16(q3.x, c67, dot2_u16(q2.x, c45, dot2_u16(q1.x, c23, dot2_u16(q0.x, c01, 32768u))));
+        acc[1] = dot2_u16(q3.y, c67, dot2_u16(q2.y, c45, dot2_u16(q1.y, c23, dot2_u16(q0.y, c01, 32768u))));
+        acc[2] = dot2_u16(q3.z, c67, dot2_u16(q2.z, c45, dot2_u16(q1.z, c23, dot2_u16(q0.z, c01, 32768u))));
+        acc[3] = dot2_u16(q3.w, c67, dot2_u16(q2.w, c45, dot2_u16(q1.w, c23, dot2_u16(q0.w, c01, 32768u))));
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -307,11 +342,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             }
         }
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            m10 += __shfl_xor(m10, d, 64);
-            m01 += __shfl_xor(m01, d, 64);
-        }
+        // wave-wide sums through the data-parallel-primitive path (no LDS traffic)
+        m10 = __ockl_wfred_add_i32(m10);
+        m01 = __ockl_wfred_add_i32(m01);
         if (lane == 0)
             s_angle[ls] = fast_atan2_deg((float)m01, (float)m10);
     }

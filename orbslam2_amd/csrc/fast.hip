@@ -155,13 +155,20 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     if (threadIdx.x == 0)
         qn = 0, sn = 0;
     // stage rows ty0-4 .. ty0+67, columns tx0-4 .. tx0+67 (word aligned: tx0 is a multiple of 64)
-    for (int i = threadIdx.x; i < IMG_H * GRP_W; i += 256) {
-        const int r = i / GRP_W, c4 = i % GRP_W;
-        const int y = ty0 - 4 + r, x = tx0 - 4 + c4 * 4;
-        uint32_t v = 0;
-        if (y >= 0 && y < h && x >= 0 && x < pitch)
-            v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * pitch + x);
-        reinterpret_cast<uint32_t *>(img)[i] = v;
+    const bool inside = tx0 >= 4 && tx0 + ORBX_FAST_W + 4 <= pitch && ty0 >= 4 && ty0 + ORBX_FAST_H + 4 <= h;
+    {
+        // 256 = 14*18 + 4: the (row, group) of a thread's next word follows without a division
+        int r = threadIdx.x / GRP_W, c4 = threadIdx.x % GRP_W;
+        for (int i = threadIdx.x; i < IMG_H * GRP_W; i += 256) {
+            const int y = ty0 - 4 + r, x = tx0 - 4 + c4 * 4;
+            uint32_t v = 0;
+            if (inside || (y >= 0 && y < h && x >= 0 && x < pitch))
+                v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * pitch + x);
+            reinterpret_cast<uint32_t *>(img)[i] = v;
+            r += 14, c4 += 4;
+            if (c4 >= GRP_W)
+                c4 -= GRP_W, r++;
+        }
     }
     __syncthreads();
     if (a.dbg_stop == 1)
@@ -170,17 +177,15 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     // ---- compass test, four pixels per thread, on staged rows 3..68 (tile rows -1..64) ----
     const int tm = a.t_low;
     const uint32_t tt = (uint32_t)tm * 0x10001u;
-    const int lane = threadIdx.x & 63;
-    for (int i0 = threadIdx.x - lane; i0 < SC_H * GRP_W; i0 += 256) {  // whole waves only: shuffles below
-        const int i = i0 + lane;
-        uint32_t pass = 0;  // bit o: pixel o of the group passed
-        int r = 0, g = 0;
-        if (i < SC_H * GRP_W) {
-            r = i / GRP_W + 3, g = i % GRP_W;  // staged row, group
+    // the whole score region lies in the detectable range for tiles away from the image border
+    const bool all_valid = tx0 - 1 >= x_lo && tx0 + ORBX_FAST_W + 1 <= x_hi && ty0 - 1 >= y_lo &&
+                           ty0 + ORBX_FAST_H + 1 <= y_hi;
+    {
+        int r = threadIdx.x / GRP_W + 3, g = threadIdx.x % GRP_W;
+        for (int i = threadIdx.x; i < SC_H * GRP_W; i += 256) {
             reinterpret_cast<uint32_t *>(sc)[r * GRP_W + g] = 0u;
             const int y = ty0 - 4 + r, xg = tx0 - 4 + 4 * g;
-            // the groups left and right of the tile hold one needed pixel each; the image border none
-            if (y >= y_lo && y < y_hi && xg + 3 >= x_lo && xg < x_hi) {
+            if (all_valid || (y >= y_lo && y < y_hi && xg + 3 >= x_lo && xg < x_hi)) {
                 const uint32_t *wrow = reinterpret_cast<const uint32_t *>(img) + r * GRP_W + g;
                 const uint32_t vw = wrow[0], upw = wrow[-3 * GRP_W], dnw = wrow[3 * GRP_W];
                 const uint32_t lw = g > 0 ? wrow[-1] : 0u, rw = g < GRP_W - 1 ? wrow[1] : 0u;
@@ -190,36 +195,29 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
                                              widen_lo(r12w), tt);
                 const uint32_t m1 = compass2(widen_hi(vw), widen_hi(dnw), widen_hi(upw), widen_hi(r4w),
                                              widen_hi(r12w), tt);
-                pass = ((m0 >> 15) & 1u) | ((m0 >> 30) & 2u) | ((m1 >> 13) & 4u) | ((m1 >> 28) & 8u);
-                // keep only pixels inside the score region and the detectable range
+                uint32_t pass = ((m0 >> 15) & 1u) | ((m0 >> 30) & 2u) | ((m1 >> 13) & 4u) | ((m1 >> 28) & 8u);
+                // the groups left and right of the tile hold one needed pixel each
+                if (g == 0)
+                    pass &= 8u;
+                if (g == GRP_W - 1)
+                    pass &= 1u;
+                if (!all_valid) {
 #pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    const int x = xg + o;
-                    if (x < x_lo || x >= x_hi || 4 * g + o < 3 || 4 * g + o > 3 + SC_W - 1)
-                        pass &= ~(1u << o);
+                    for (int o = 0; o < 4; o++)
+                        if (xg + o < x_lo || xg + o >= x_hi)
+                            pass &= ~(1u << o);
+                }
+                if (pass) {
+                    int k = atomicAdd(&qn, __popc(pass));
+#pragma unroll
+                    for (int o = 0; o < 4; o++)
+                        if (pass & (1u << o))
+                            queue[k++] = (uint16_t)((r << 7) | (4 * g + o));
                 }
             }
-        }
-        // ordered compaction: one LDS atomic per wave and round
-        const int cnt = __popc(pass);
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int tmp = __shfl_up(incl, d, 64);
-            if (lane >= d)
-                incl += tmp;
-        }
-        const int wave_total = __shfl(incl, 63, 64);
-        int wbase = 0;
-        if (wave_total > 0) {
-            if (lane == 63)
-                wbase = atomicAdd(&qn, wave_total);
-            wbase = __shfl(wbase, 63, 64);
-            int k = wbase + incl - cnt;
-#pragma unroll
-            for (int o = 0; o < 4; o++)
-                if (pass & (1u << o))
-                    queue[k++] = (uint16_t)((r << 7) | (4 * g + o));
+            r += 14, g += 4;
+            if (g >= GRP_W)
+                g -= GRP_W, r++;
         }
     }
     __syncthreads();

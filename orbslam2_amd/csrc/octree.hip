@@ -258,11 +258,29 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
                 L.order()[L.prank()[i]] = i;
 
         // ---- key counts of the four children (:551-565) ----
-        for_keys([&](int j, int k) {
-            const int i = NODE(j, k);
-            if (i != OCT_DROPPED && cnt[i] >= 2)
-                atomicAdd(&L.cc(quadrant_of(XY(j, k), bx[i], by[i]))[i], 1);
-        });
+        if constexpr (KMAX > 0) {
+            // all reads first, then all atomics: the reads of different candidates overlap
+            int enc[KR];
+#pragma unroll
+            for (int j = 0; j < KMAX; j++) {
+                const int k = tid + 256 * j;
+                const int i = rnode[j];
+                const bool live = k < n && i != OCT_DROPPED;
+                const int ii = live ? i : 0;
+                const int c = cnt[ii], b_x = bx[ii], b_y = by[ii];
+                enc[j] = (live && c >= 2) ? (ii * 4 + quadrant_of(rxy[j], b_x, b_y)) : -1;
+            }
+#pragma unroll
+            for (int j = 0; j < KMAX; j++)
+                if (enc[j] >= 0)
+                    atomicAdd(&L.cc(enc[j] & 3)[enc[j] >> 2], 1);
+        } else {
+            for_keys([&](int j, int k) {
+                const int i = NODE(j, k);
+                if (i != OCT_DROPPED && cnt[i] >= 2)
+                    atomicAdd(&L.cc(quadrant_of(XY(j, k), bx[i], by[i]))[i], 1);
+            });
+        }
         __syncthreads();
 
         // ---- how many nodes are processed: all, or up to the one that brings the list to N ----
@@ -342,17 +360,15 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             const int i = NODE(j, k);
             if (i == OCT_DROPPED)
                 return;
+            // branch-free: every operand is read, the result is selected
             const int r = L.prank()[i];
-            if (r >= 0 && r < t) {
-                const int q = quadrant_of(XY(j, k), bx[i], by[i]);
-                const int c[4] = {L.cc(0)[i], L.cc(1)[i], L.cc(2)[i], L.cc(3)[i]};
-                const int nz = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
-                int before = 0;
-                for (int qq = 0; qq < q; qq++)
-                    before += c[qq] > 0;
-                SET_NODE(j, k, children - L.nzs()[r] + (nz - 1 - before));
-            } else
-                SET_NODE(j, k, L.spos()[i]);
+            const bool moved = r >= 0 && r < t;
+            const int q = quadrant_of(XY(j, k), bx[i], by[i]);
+            const int c0 = L.cc(0)[i] > 0, c1 = L.cc(1)[i] > 0, c2 = L.cc(2)[i] > 0, c3 = L.cc(3)[i] > 0;
+            const int nz = c0 + c1 + c2 + c3;
+            const int before = (q > 0 ? c0 : 0) + (q > 1 ? c1 : 0) + (q > 2 ? c2 : 0);
+            const int child = children - L.nzs()[moved ? r : 0] + (nz - 1 - before);
+            SET_NODE(j, k, moved ? child : L.spos()[i]);
         });
         __syncthreads();
         size = new_size;

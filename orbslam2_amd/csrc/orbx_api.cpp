@@ -181,8 +181,8 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
         L.patch_size = (int)(31 * ex->sf[l]);
         L.xtab_off = xt;
         L.ytab_off = yt;
-        xt += L.w;
-        yt += L.h;
+        xt += align_up(L.w, 4);  // a thread reads the coefficients of 4 columns / 2 rows at once
+        yt += align_up(L.h, 2);
     }
     g->cells_per_frame = cells;
     g->tiles_per_frame = tiles;
@@ -202,13 +202,13 @@ static void build_resize_tables(const OrbxGeom &g, std::vector<OrbxXCoef> &xt, s
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &D = g.lv[l];
         const size_t x0 = xt.size(), y0 = yt.size();
-        xt.resize(x0 + D.w);
-        yt.resize(y0 + D.h);
+        xt.resize(x0 + align_up(D.w, 4));
+        yt.resize(y0 + align_up(D.h, 2));
         if (l == 0) {
-            for (int i = 0; i < D.w; i++)
-                xt[x0 + i] = OrbxXCoef{i, 2048, 0};
-            for (int i = 0; i < D.h; i++)
-                yt[y0 + i] = OrbxYCoef{i, i, 2048, 0};
+            for (int i = 0; i < align_up(D.w, 4); i++)
+                xt[x0 + i] = OrbxXCoef{std::min(i, D.w - 1), 2048, 0};
+            for (int i = 0; i < align_up(D.h, 2); i++)
+                yt[y0 + i] = OrbxYCoef{std::min(i, D.h - 1), std::min(i, D.h - 1), 2048, 0};
             continue;
         }
         const OrbxLevel &S = g.lv[l - 1];
@@ -246,6 +246,10 @@ static void build_resize_tables(const OrbxGeom &g, std::vector<OrbxXCoef> &xt, s
             c.b1 = sat_short(round_half_even(fy * 2048));
             yt[y0 + dy] = c;
         }
+        for (int i = D.w; i < align_up(D.w, 4); i++)  // padding: copies of the last entry
+            xt[x0 + i] = xt[x0 + D.w - 1];
+        for (int i = D.h; i < align_up(D.h, 2); i++)
+            yt[y0 + i] = yt[y0 + D.h - 1];
     }
 }
 
@@ -340,7 +344,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     if (e == hipSuccess) e = dmalloc(&b.status, (size_t)ORBX_ST_COUNT);
     int xt = 0, yt = 0;
     for (int l = 0; l < g.nlevels; l++)
-        xt += g.lv[l].w, yt += g.lv[l].h;
+        xt += align_up(g.lv[l].w, 4), yt += align_up(g.lv[l].h, 2);
     ex->xtab_cap = xt;
     ex->ytab_cap = yt;
     if (e == hipSuccess) e = dmalloc(&ex->d_xtab, (size_t)xt);

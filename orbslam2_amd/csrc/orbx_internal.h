@@ -59,7 +59,7 @@ struct OrbxXCoef {
 };
 struct OrbxYCoef {
     int sy0, sy1;
-    short b0, b1;
+    int b0, b1;
 };
 
 // device status words written by kernels (index into the status array)
