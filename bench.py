@@ -34,7 +34,7 @@ OPS_PER_PAIR = 16
 
 WORKLOADS = {
     # name: (width, height, nfeatures, frames per batch)
-    "kitti_1241x376_2000kp": (1241, 376, 2000, 128),
+    "kitti_1241x376_2000kp": (1241, 376, 2000, 256),
     "euroc_752x480_1000kp": (752, 480, 1000, 128),
     "tum_640x480_1000kp": (640, 480, 1000, 128),
 }
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="kitti_1241x376_2000kp", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
-    ap.add_argument("--instances", type=int, default=2, help="extractor instances (streams) sharing a step's frames")
+    ap.add_argument("--instances", type=int, default=4, help="extractor instances (streams) sharing a step's frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -112,9 +112,10 @@ def main():
     for f in range(batch):
         host[f] = orbx.synth_image(0x0B5EED00 + rank * 100003 + f, w, h, 0, stride=stride)
     frames = torch.from_numpy(host).cuda()
-    # A stereo pair batch: the left and the right images go through two extractor instances on two
+    # A stereo pair batch: left and right images go through separate extractor instances on separate
     # streams, as the reference runs mpORBextractorLeft / mpORBextractorRight in two threads
-    # (src/Frame.cc:79-82).  Each instance takes half of the step's frames.
+    # (src/Frame.cc:79-82).  The step's frames are split evenly over the instances (default 4: two
+    # left/right pairs of extractors), whose kernels the GPU overlaps.
     ninst = max(1, args.instances)
     half = (batch + ninst - 1) // ninst
     streams = [torch.cuda.Stream() for _ in range(ninst)]

@@ -2,8 +2,6 @@
 // unblurred level, 256-bit steered BRIEF on the blurred level, scale-back and level-major output
 // (GaussianBlur call src/ORBextractor.cc:1157-1159; IC_Angle :93-124; computeOrbDescriptor :127-169;
 // assembly :1147-1181 of the reference).
-#include <cstdlib>
-
 #include "orbx_internal.h"
 
 extern "C" __device__ int __ockl_wfred_add_i32(int);  // wave-wide integer sum (device library)
@@ -200,7 +198,6 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 struct DescArgs {
     int nlevels, slab, kp_per_frame, out_cap;
     OrbxLevel0 l0;
-    int dbg_stop;  // timing experiments only: 1..3 = leave after locating / after the moments / after cos,sin
     int pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], kp_base[ORBX_MAX_LEVELS], patch_size[ORBX_MAX_LEVELS];
     float scale[ORBX_MAX_LEVELS];
 };
@@ -273,8 +270,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_xy[threadIdx.x] = kept_xy[(size_t)f * a.kp_per_frame + ki];
     }
     __syncthreads();
-    if (a.dbg_stop == 1)
-        return;
     // everything a window fetch needs comes from LDS: no global load sits in front of it
     auto locate = [&](int slot, int &lvl, int &x, int &y, size_t &ki, int &pitch, int &off) {
         const int ls = slot - base;
@@ -349,8 +344,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             s_angle[ls] = fast_atan2_deg((float)m01, (float)m10);
     }
     __syncthreads();
-    if (a.dbg_stop == 2)
-        return;
     if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         const float rad = __fmul_rn(s_angle[threadIdx.x], factorPI);
@@ -358,8 +351,6 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_sa[threadIdx.x] = (float)sin((double)rad);
     }
     __syncthreads();
-    if (a.dbg_stop == 3)
-        return;
 
     // ---- steered BRIEF: lane L evaluates tests L, L+64, L+128, L+192; a ballot yields 64 descriptor bits ----
     float px0[4], py0[4], px1[4], py1[4];
@@ -435,8 +426,6 @@ hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStre
     DescArgs a;
     a.nlevels = g.nlevels, a.slab = g.slab, a.kp_per_frame = g.kp_per_frame, a.out_cap = g.out_cap;
     a.l0 = b.l0;
-    const char *dbg = getenv("ORBX_DEBUG_DESCRIBE_STOP");
-    a.dbg_stop = dbg ? atoi(dbg) : 0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.pitch[l] = L.pitch, a.off[l] = L.off, a.kp_base[l] = L.kp_base, a.patch_size[l] = L.patch_size;

@@ -18,8 +18,6 @@
 // ring) against the four compass points, two pixels per packed 16-bit operation (a 9-arc contains at
 // least one pixel of each antipodal pair); queue the few that pass; compute A only for those, both
 // polarities at once with packed 16-bit min/max; suppress non-maxima; append.
-#include <cstdlib>
-
 #include "orbx_internal.h"
 
 #define IMG_W (ORBX_FAST_W + 8)  // 72 staged columns: tx0-4 .. tx0+67
@@ -116,7 +114,6 @@ struct FastArgs {
     int nlevels, slab, cells_per_frame, cand_per_frame, tiles_per_frame;
     OrbxLevel0 l0;
     int t_low, t_ini;  // min(iniThFAST, minThFAST) and iniThFAST, clamped to [1,255]
-    int dbg_stop;      // timing experiments only: 1..4 = leave after staging / compass / score / before the append
     int tile_base[ORBX_MAX_LEVELS + 1];
     int tiles_x[ORBX_MAX_LEVELS];
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
@@ -171,8 +168,6 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         }
     }
     __syncthreads();
-    if (a.dbg_stop == 1)
-        return;
 
     // ---- compass test, four pixels per thread, on staged rows 3..68 (tile rows -1..64) ----
     const int tm = a.t_low;
@@ -221,8 +216,6 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         }
     }
     __syncthreads();
-    if (a.dbg_stop == 2)
-        return;
 
     // ---- full score for the queued pixels ----
     const int nq = qn;
@@ -234,8 +227,6 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             sc[r * IMG_W + c] = (uint8_t)A;
     }
     __syncthreads();
-    if (a.dbg_stop == 3)
-        return;
 
     // ---- non-maximum suppression inside the pixel's cell, on the tile proper ----
     // Survivors go to the tile's own list (no global atomics); a later pass concatenates the lists.
@@ -268,7 +259,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             if (l) m = max(m, (int)p[IMG_W - 1]);
             if (rr) m = max(m, (int)p[IMG_W + 1]);
         }
-        if (A > m && a.dbg_stop != 4) {
+        if (A > m) {
             const int cell = ci * a.ncols[lvl] + cj;
             const int k = atomicAdd(&sn, 1);  // LDS; at most ORBX_TILE_CAP strict per-cell maxima fit a tile
             // x | y<<12 relative to (16,16) | cornerScore<<24 ; order key of the reference's candidate list
@@ -345,8 +336,6 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
     // its non-corner neighbours, which is A > 1
     a.t_ini = min(max(g.ini_th, 1), 255);
     a.t_low = min(a.t_ini, min(max(g.min_th, 1), 255));
-    const char *dbg = getenv("ORBX_DEBUG_FAST_STOP");
-    a.dbg_stop = dbg ? atoi(dbg) : 0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.tile_base[l] = L.ftile_base;

@@ -46,6 +46,9 @@ struct orbx_extractor {
     hipStream_t own_stream, stream;
     hipStream_t aux_stream;        // the blur runs here, beside detection and distribution
     hipEvent_t ev_pyramid, ev_blur;
+    uint8_t *h_stage;              // pinned staging for host frames (level-0 layout), allocated on first use
+    size_t h_stage_bytes;
+    hipEvent_t ev_staged;          // the uploads out of h_stage have finished
     float sf[ORBX_MAX_LEVELS], inv[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], invsig2[ORBX_MAX_LEVELS];
     int quota[ORBX_MAX_LEVELS];
     OrbxGeom cap_geom;  // geometry of max_width x max_height: sizes every buffer
@@ -296,7 +299,9 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->profiling = false;
     ex->prof_used = 0;
     ex->own_stream = ex->stream = ex->aux_stream = nullptr;
-    ex->ev_pyramid = ex->ev_blur = nullptr;
+    ex->ev_pyramid = ex->ev_blur = ex->ev_staged = nullptr;
+    ex->h_stage = nullptr;
+    ex->h_stage_bytes = 0;
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
@@ -320,6 +325,8 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
         e = hipEventCreateWithFlags(&ex->ev_pyramid, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipEventCreateWithFlags(&ex->ev_blur, hipEventDisableTiming);
+    if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&ex->ev_staged, hipEventDisableTiming);
     ex->stream = ex->own_stream;
     const OrbxGeom &g = ex->cap_geom;
     const size_t B = (size_t)p.max_batch;
@@ -354,6 +361,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
         free_buffers(ex);
         if (ex->ev_pyramid) (void)hipEventDestroy(ex->ev_pyramid);
         if (ex->ev_blur) (void)hipEventDestroy(ex->ev_blur);
+        if (ex->ev_staged) (void)hipEventDestroy(ex->ev_staged);
         if (ex->aux_stream) (void)hipStreamDestroy(ex->aux_stream);
         if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
         delete ex;
@@ -377,6 +385,8 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *ex)
     free_buffers(ex);
     if (ex->ev_pyramid) (void)hipEventDestroy(ex->ev_pyramid);
     if (ex->ev_blur) (void)hipEventDestroy(ex->ev_blur);
+    if (ex->ev_staged) (void)hipEventDestroy(ex->ev_staged);
+    if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->aux_stream) (void)hipStreamDestroy(ex->aux_stream);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     delete ex;
@@ -521,13 +531,35 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
     if (rc != ORBX_OK)
         return rc;
     const OrbxLevel &L0 = ex->geom.lv[0];
+    // Pageable rows go through a pinned staging buffer in the level-0 layout: one contiguous
+    // asynchronous copy per frame (a strided copy out of pageable memory costs milliseconds).
+    const size_t frame_bytes = (size_t)L0.pitch * L0.h;
+    const size_t need = frame_bytes * (size_t)ex->p.max_batch;
+    if (ex->h_stage_bytes < need) {
+        HIP_TRY(hipStreamSynchronize(ex->stream));
+        if (ex->h_stage)
+            HIP_TRY(hipHostFree(ex->h_stage));
+        ex->h_stage = nullptr;
+        ex->h_stage_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&ex->h_stage, need, hipHostMallocDefault));
+        ex->h_stage_bytes = need;
+    } else {
+        HIP_TRY(hipEventSynchronize(ex->ev_staged));  // the previous batch has left the staging buffer
+    }
     HIP_TRY(prof_mark(ex, 0, 0, ex->stream));
     for (int f = 0; f < batch; f++) {
         if (!images[f])
             return ORBX_E_ARG;
-        HIP_TRY(hipMemcpy2DAsync(ex->buf.pyr + (size_t)f * ex->geom.slab + L0.off, L0.pitch, images[f], stride_bytes,
-                                 width, height, hipMemcpyHostToDevice, ex->stream));
+        uint8_t *st = ex->h_stage + (size_t)f * frame_bytes;
+        if (stride_bytes == L0.pitch)
+            memcpy(st, images[f], frame_bytes);
+        else
+            for (int y = 0; y < height; y++)
+                memcpy(st + (size_t)y * L0.pitch, images[f] + (size_t)y * stride_bytes, width);
+        HIP_TRY(hipMemcpyAsync(ex->buf.pyr + (size_t)f * ex->geom.slab + L0.off, st, frame_bytes,
+                               hipMemcpyHostToDevice, ex->stream));
     }
+    HIP_TRY(hipEventRecord(ex->ev_staged, ex->stream));
     ex->buf.l0 = OrbxLevel0{ex->buf.pyr + L0.off, (long long)ex->geom.slab, L0.pitch};
     HIP_TRY(prof_mark(ex, 0, 1, ex->stream));
     return run_pipeline(ex);

@@ -226,3 +226,76 @@ def test_gpu_reproduces_golden_fixtures():
             ko, do = orc.extract(img, e["nfeatures"], 1.2, 8, 20, 7)
             compare_frame(kg, dg, ko, do)
         ex.close()
+
+
+def test_error_codes_and_capacity(oracle):
+    import ctypes as C
+    from orbslam2_amd import _lib as L
+    lib = L.lib()
+    ex = make_extractor(TUM, 640, 480)
+    img = orbx.synth_image(SEED, 640, 480, 0)
+    # caller buffers too small: the required count comes back, nothing else is written
+    kps = np.zeros(10, L.KEYPOINT_DTYPE)
+    desc = np.full((10, 32), 7, np.uint8)
+    n = C.c_int(0)
+    rc = lib.orbx_extract(ex._h, L.ptr(img), 640, 480, 640, L.ptr(kps), L.ptr(desc), 10, C.byref(n))
+    assert rc == L.E_CAPACITY and n.value > 900 and (desc == 7).all()
+    # larger than the workspace the handle was created for
+    big = orbx.synth_image(SEED, 800, 600, 0)
+    with pytest.raises(orbx.OrbxError) as e:
+        ex(big)
+    assert e.value.code == L.E_CAPACITY
+    # a portrait image whose detection region has round(width/height) == 0: the reference divides by zero
+    tall = make_extractor(TUM, 100, 400)
+    with pytest.raises(orbx.OrbxError) as e:
+        tall(orbx.synth_image(SEED, 100, 400, 0))
+    assert e.value.code == L.E_GEOMETRY
+    with pytest.raises(ValueError):
+        oracle.extract(orbx.synth_image(SEED, 100, 400, 0), 1000, 1.2, 8, 20, 7)
+    # a stride smaller than the width is an argument error
+    rc = lib.orbx_extract(ex._h, L.ptr(img), 640, 480, 600, L.ptr(kps), L.ptr(desc), 10, C.byref(n))
+    assert rc == L.E_ARG
+    # results of the last good call survive a failed call's checks
+    k, d = ex(img)
+    ko, do = oracle_extract(oracle, img, TUM)
+    compare_frame(k, d, ko, do)
+
+
+def test_two_handles_from_two_threads(oracle):
+    """The stereo constructor of Frame runs the left and the right extractor in two threads
+    (src/Frame.cc:79-82): two handles must work concurrently."""
+    import threading
+    w, h = 752, 480
+    imgs = [orbx.synth_image(SEED + 100 + i, w, h, 0) for i in range(2)]
+    exs = [make_extractor(EUROC_STEREO, w, h) for _ in range(2)]
+    out = [None, None]
+
+    def run(i):
+        for _ in range(5):
+            out[i] = exs[i](imgs[i])
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(2):
+        ko, do = oracle_extract(oracle, imgs[i], EUROC_STEREO)
+        compare_frame(out[i][0], out[i][1], ko, do)
+
+
+def test_scale_tables_match_oracle(oracle):
+    ex = make_extractor(KITTI, 1241, 376)
+    sf, inv, s2, is2 = oracle.scale_tables(1.2, 8)
+    assert np.array_equal(ex.GetScaleFactors(), sf) and np.array_equal(ex.GetInverseScaleFactors(), inv)
+    assert np.array_equal(ex.GetScaleSigmaSquares(), s2) and np.array_equal(ex.GetInverseScaleSigmaSquares(), is2)
+    assert list(ex.features_per_level()) == list(oracle.features_per_level(2000, 1.2, 8))
+    assert ex.GetLevels() == 8 and abs(ex.GetScaleFactor() - 1.2) < 1e-6
+    # other pyramid shapes: 4 levels of scale 1.5, 12 levels of scale 1.1
+    for nl, sc in [(4, 1.5), (12, 1.1)]:
+        p = dict(nfeatures=800, scale=sc, nlevels=nl, ini=20, minth=7)
+        img = orbx.synth_image(SEED + nl, 640, 480, 0)
+        e2 = make_extractor(p, 640, 480)
+        kg, dg = e2(img)
+        ko, do = oracle_extract(oracle, img, p)
+        compare_frame(kg, dg, ko, do)
