@@ -7,8 +7,14 @@ A step = one pass of the extractor over one batch of synthetic KITTI-shape frame
 ranks share nothing on the data path (weak scaling); torch.distributed only provides the barrier
 and the max-over-ranks of the elapsed time.
 
+After the timed region one extractor instance runs the same launches alone with stage profiling on
+(the library then keeps every stage on one stream), which gives exclusive per-kernel durations.
+`--exclusive` runs the timed region itself that way (one instance, no overlap), so that a
+`rocprofv3 --kernel-trace --stats` of that command shows the same per-kernel averages.
+
 Extra objects on the JSON line:
-  roofline      dominant extractor kernel: algorithmic bytes per launch / its HIP-event duration vs 8 TB/s
+  roofline      dominant extractor kernel: algorithmic bytes per launch / its exclusive HIP-event duration
+                vs 8 TB/s; `traffic` = HBM bytes per launch from committed PMC passes (profiles/), if any
   cpu_baseline  the CPU oracle (oracle/, a scalar restatement of the reference) on a bounded sample
   stages        per-stage milliseconds per batch (HIP events on the extractor's stream)
   hamming       brute-force top-2 of 2000 queries against a 1M-descriptor database on this GPU
@@ -76,6 +82,8 @@ def main():
     ap.add_argument("--workload", default="kitti_1241x376_2000kp", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="frames per step per GPU (default: workload's)")
     ap.add_argument("--instances", type=int, default=4, help="extractor instances (streams) sharing a step's frames")
+    ap.add_argument("--exclusive", action="store_true",
+                    help="one instance, stages serialised and profiled inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -116,7 +124,7 @@ def main():
     # streams, as the reference runs mpORBextractorLeft / mpORBextractorRight in two threads
     # (src/Frame.cc:79-82).  The step's frames are split evenly over the instances (default 4: two
     # left/right pairs of extractors), whose kernels the GPU overlaps.
-    ninst = max(1, args.instances)
+    ninst = 1 if args.exclusive else max(1, args.instances)
     half = (batch + ninst - 1) // ninst
     streams = [torch.cuda.Stream() for _ in range(ninst)]
     exs = [orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=half, device=local_rank)
@@ -137,28 +145,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.exclusive:
+        ex.profile(True)
     for _ in range(args.warmup):
         step()
     barrier()
-    for e in exs:
-        e.profile(True)
+    if args.exclusive:
+        ex.profile(True)  # drops the warm-up samples
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    for e in exs:
-        e.profile(False)
     el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     n_kp = float(np.mean(np.concatenate([e.batch_counts()[0] for e in exs])))
-    # per-launch stage times of the left extractor (half a step's frames per launch)
+    # exclusive per-stage times: instance 0 alone, same launch size, stages serialised by the library
+    if not args.exclusive:
+        ex.profile(True)
+        fr0, nb0 = eyes[0]
+        for _ in range(max(args.steps, 5)):
+            ex.extract_batch_device(fr0.data_ptr(), nb0, w, h, stride, h * stride)
+        torch.cuda.synchronize()
     stage_ms, nprof = ex.stage_times()
+    ex.profile(False)
     stage_ms = {k: v / max(nprof, 1) for k, v in stage_ms.items()}
-    launch_frames = half
+    launch_frames = eyes[0][1]
 
     hamming_sharded = None
     if world > 1 and not args.no_hamming:
@@ -174,16 +189,27 @@ def main():
     frames_total = world * batch * args.steps
     fps = frames_total / elapsed
     per_stage_bytes, frame_bytes = algorithmic_bytes(w, h, n_kp)
-    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    # the dominant kernel: stages that are one kernel launch (resize is a chain of 7 smaller launches;
+    # "octree" is the distribution kernel plus a ~20 us compaction kernel and moves almost no data)
+    single = {"fast": "k_fast", "blur": "k_blur", "describe": "k_describe"}
+    dom = max(single, key=lambda k: stage_ms[k])
     dom_bytes = per_stage_bytes[dom] * launch_frames
     dom_s = stage_ms[dom] * 1e-3
     achieved = dom_bytes / dom_s / 1e9 if dom_s > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+    traffic, traffic_src = committed_traffic(single[dom], args.workload, launch_frames)
+    roofline = {"bound": "hbm", "kernel": single[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms_per_launch": round(stage_ms[dom], 4),
                 "algorithmic_bytes_per_launch": dom_bytes,
+                "limiter": "vector-ALU issue (integer), not HBM: see valu_* fields",
                 "pipeline_achieved_GBs": round(fps / world * frame_bytes / 1e9, 2),
                 "pipeline_frac": round(fps / world * frame_bytes / 1e9 / HBM_PEAK_GBS, 5)}
+    valu = committed_valu(single[dom], args.workload, launch_frames)
+    if valu is not None and dom_s > 0:
+        roofline["valu_wave_instr_per_launch"] = valu
+        roofline["valu_lane_ops_per_s"] = round(valu * 64 / dom_s / 1e12, 3)
+        roofline["valu_frac_of_measured_issue_rate"] = round(valu * 64 / dom_s / VALU_LANE_OPS_MEASURED, 4)
 
     out = {
         "metric": "ORB frames/s @KITTI 1241x376 2000 kp (1/8 GPU); Hamming matches/s; % roofline",
@@ -194,8 +220,10 @@ def main():
                    "scale_factor": 1.2, "ini_th_fast": 20, "min_th_fast": 7, "mean_keypoints_per_frame": n_kp,
                    "parallelism": "frame-batch shards, no collective"},
         "roofline": roofline,
-        "stages_ms_per_launch": {k: round(v, 4) for k, v in stage_ms.items()},
+        "stages_ms_per_launch_exclusive": {k: round(v, 4) for k, v in stage_ms.items()},
         "frames_per_launch": launch_frames,
+        "timed_region": "exclusive (1 instance, serialised stages)" if args.exclusive else
+                        "%d instances on %d streams, blur overlapped" % (ninst, 2 * ninst),
     }
 
     if world == 1 and not args.no_hamming:
@@ -208,6 +236,32 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _committed(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)
+
+
+def committed_traffic(kernel, workload, launch_frames):
+    """HBM bytes per launch of `kernel` from the committed counter passes (profiles/traffic.json holds
+    per-frame bytes measured with TCC FETCH_SIZE / WRITE_SIZE at the same launch size); None if absent."""
+    t = _committed("traffic.json")
+    if not t or t.get("workload") != workload or kernel not in t.get("kernels", {}):
+        return None, None
+    k = t["kernels"][kernel]
+    return round(k["hbm_bytes_per_frame"] * launch_frames, 1), t.get("source")
+
+
+def committed_valu(kernel, workload, launch_frames):
+    t = _committed("traffic.json")
+    if not t or t.get("workload") != workload or kernel not in t.get("kernels", {}):
+        return None
+    v = t["kernels"][kernel].get("valu_wave_instr_per_frame")
+    return None if v is None else v * launch_frames
 
 
 def bench_hamming(orbx, torch, stream):

@@ -118,12 +118,14 @@ int orbx_batch_device_results(orbx_extractor *ex, const orbx_keypoint **d_keypoi
                               const int32_t **d_counts, int *max_keypoints);
 
 /* Per-stage device time of the batches extracted while profiling is enabled, measured with HIP
- * events recorded around each stage on the stream it runs on (the blur runs on a second stream
- * beside detection and distribution, so stage times can overlap).  The reference has no counterpart
- * (it only wall-clocks whole Track calls, Examples/Stereo/stereo_kitti.cc:80-97).
- * Stages: 0 ingest (copy of the caller's frames into level 0), 1 resize (levels 1..n-1),
- * 2 fast (score, per-cell non-maximum suppression, candidate append), 3 octree (threshold fallback and
- * quadtree distribution), 4 blur, 5 describe (orientation, rBRIEF, output). */
+ * events recorded around each stage.  Normally the blur runs on a second stream beside detection
+ * and distribution; while profiling is enabled every stage runs on the main stream, so the stage
+ * times are exclusive (and a batch takes a little longer than unprofiled).  The reference has no
+ * counterpart (it only wall-clocks whole Track calls, Examples/Stereo/stereo_kitti.cc:80-97).
+ * Stages: 0 ingest (copy of the caller's frames into level 0), 1 resize (levels 1..n-1, one kernel
+ * per level), 2 fast (the detection kernel alone: score, per-cell non-maximum suppression, tile
+ * lists), 3 octree (candidate compaction, threshold fallback and quadtree distribution), 4 blur (one
+ * kernel), 5 describe (orientation, rBRIEF, output; one kernel). */
 #define ORBX_NSTAGES 6
 const char *orbx_stage_name(int stage);
 int orbx_extractor_profile(orbx_extractor *ex, int enable); /* enabling clears earlier samples */

@@ -323,7 +323,8 @@ __global__ __launch_bounds__(64) void k_gather(const int *__restrict__ tile_cnt,
     }
 }
 
-hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
+// part 0: clear the per-cell flags, 1: detection, 2: compaction of the tile lists
+hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s, int part)
 {
     FastArgs a;
     a.nlevels = g.nlevels;
@@ -345,16 +346,14 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
         a.cand_base[l] = L.cand_base, a.cand_cap[l] = L.cand_cap;
     }
     a.tile_base[g.nlevels] = g.ftiles_per_frame;
-    hipError_t e = hipSuccess;
-    if (g.cells_per_frame > 0) {
-        e = hipMemsetAsync(b.cell_flag, 0, (size_t)g.batch * g.cells_per_frame, s);
-        if (e != hipSuccess)
-            return e;
-    }
+    if (part == 0)
+        return g.cells_per_frame > 0 ? hipMemsetAsync(b.cell_flag, 0, (size_t)g.batch * g.cells_per_frame, s)
+                                     : hipSuccess;
     dim3 grid(g.ftiles_per_frame, g.batch);
-    k_fast<<<grid, 256, 0, s>>>(b.pyr, b.tile_cnt, b.tile_list, b.cell_flag, a);
-    if ((e = hipGetLastError()) != hipSuccess)
-        return e;
+    if (part == 1) {
+        k_fast<<<grid, 256, 0, s>>>(b.pyr, b.tile_cnt, b.tile_list, b.cell_flag, a);
+        return hipGetLastError();
+    }
     k_gather<<<grid, 64, 0, s>>>(b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.status, a);
     return hipGetLastError();
 }

@@ -469,26 +469,35 @@ static int run_pipeline(orbx_extractor *ex)
     const OrbxGeom &g = ex->geom;
     const OrbxBuffers &b = ex->buf;
     hipStream_t s = ex->stream;
-    hipStream_t s2 = ex->aux_stream;
+    // The blur only needs the pyramid: it runs on the second stream beside detection and
+    // distribution.  While profiling, every stage runs on the main stream so that the stage times
+    // are exclusive; "fast" and "blur" then bracket exactly one kernel each.
+    const bool overlap = !ex->profiling;
+    hipStream_t s2 = overlap ? ex->aux_stream : s;
     HIP_TRY(hipMemsetAsync(b.status, 0, ORBX_ST_COUNT * sizeof(int), s));
+    HIP_TRY(orbx_launch_fast(g, b, s, 0));
     HIP_TRY(prof_mark(ex, 1, 0, s));
     for (int l = 1; l < g.nlevels; l++)
         HIP_TRY(orbx_launch_resize(l, g, b, s));
     HIP_TRY(prof_mark(ex, 1, 1, s));
-    // the blur only needs the pyramid: it runs on the second stream beside detection and distribution
-    HIP_TRY(hipEventRecord(ex->ev_pyramid, s));
-    HIP_TRY(hipStreamWaitEvent(s2, ex->ev_pyramid, 0));
+    if (overlap) {
+        HIP_TRY(hipEventRecord(ex->ev_pyramid, s));
+        HIP_TRY(hipStreamWaitEvent(s2, ex->ev_pyramid, 0));
+    }
     HIP_TRY(prof_mark(ex, 4, 0, s2));
     HIP_TRY(orbx_launch_blur(g, b, s2));
     HIP_TRY(prof_mark(ex, 4, 1, s2));
-    HIP_TRY(hipEventRecord(ex->ev_blur, s2));
+    if (overlap)
+        HIP_TRY(hipEventRecord(ex->ev_blur, s2));
     HIP_TRY(prof_mark(ex, 2, 0, s));
-    HIP_TRY(orbx_launch_fast(g, b, s));
+    HIP_TRY(orbx_launch_fast(g, b, s, 1));
     HIP_TRY(prof_mark(ex, 2, 1, s));
     HIP_TRY(prof_mark(ex, 3, 0, s));
+    HIP_TRY(orbx_launch_fast(g, b, s, 2));
     HIP_TRY(orbx_launch_octree(g, b, s));
     HIP_TRY(prof_mark(ex, 3, 1, s));
-    HIP_TRY(hipStreamWaitEvent(s, ex->ev_blur, 0));
+    if (overlap)
+        HIP_TRY(hipStreamWaitEvent(s, ex->ev_blur, 0));
     HIP_TRY(prof_mark(ex, 5, 0, s));
     HIP_TRY(orbx_launch_describe(g, b, s));
     HIP_TRY(prof_mark(ex, 5, 1, s));

@@ -100,7 +100,7 @@ struct OrbxBuffers {
 hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, const OrbxGeom &g, const OrbxBuffers &b,
                               hipStream_t s);
 hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
-hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s, int part);
 hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the evidence kept under profiles/: the default bench line, kernel-trace statistics of the
+# default and of the exclusive (serialised, one instance) bench command, and separate counter passes
+# (FETCH_SIZE, WRITE_SIZE, instruction counts) of the exclusive command plus the counter calibration.
+# Usage (on the GPU box, from the repository root): bash tools/collect_profiles.sh <out-dir-under-gpurun_out>
+set -o pipefail
+OUT=$PWD/gpurun_out/${1:-r01}
+mkdir -p "$OUT"
+REPO=$PWD
+export TMPDIR=/tmp
+EXCL="$REPO/bench.py --exclusive --steps 10 --warmup 2 --no-cpu-baseline --no-hamming"
+timeout -k 10 300 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || exit 1
+timeout -k 10 200 python3 bench.py --exclusive --no-cpu-baseline > "$OUT/bench_exclusive.json" 2>> "$OUT/bench_default.err" || exit 1
+cd /tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- python3 $REPO/bench.py --no-cpu-baseline > "$OUT/trace_default.log" 2>&1 || exit 1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_exclusive" -- python3 $REPO/bench.py --exclusive --no-cpu-baseline > "$OUT/trace_exclusive.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $EXCL > "$OUT/pmc_fetch.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $EXCL > "$OUT/pmc_write.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python3 $EXCL > "$OUT/pmc_sq.log" 2>&1 || exit 1
+timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal_fetch" -- $REPO/tools/ubench_fetch > "$OUT/cal_fetch.log" 2>&1 || exit 1
+timeout -s KILL 60 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cal_write" -- $REPO/tools/ubench_fetch > "$OUT/cal_write.log" 2>&1 || exit 1
+echo collected
