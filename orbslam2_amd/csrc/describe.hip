@@ -9,7 +9,7 @@ extern "C" __device__ int __ockl_wfred_add_i32(int);  // wave-wide integer sum (
 // ---------------------------------------------------------------- blur
 
 struct BlurArgs {
-    int nlevels, slab, variant;
+    int nlevels, slab, variant, batch;
     OrbxLevel0 l0;
     int tile_base[ORBX_MAX_LEVELS + 1];
     int tiles_x[ORBX_MAX_LEVELS];
@@ -26,11 +26,13 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
-#define BL_W 64
-#define BL_H 16
-#define BL_SW (BL_W + 8)   // staged columns tx0-4 .. tx0+67 (word aligned; 3 needed each side)
-#define BL_SH (BL_H + 6)   // staged rows ty0-3 .. ty0+18 (22 rows = 11 row pairs)
+#define BL_W ORBX_FT_W          // 128 output columns per tile
+#define BL_H ORBX_FT_H          // 32 output rows per tile
+#define BL_LEFT 16              // staged columns start at tx0-16 (16-byte aligned); 3 are needed
+#define BL_SWORDS 40            // staged words per row: columns tx0-16 .. tx0+143
+#define BL_SH (BL_H + 6)        // staged rows ty0-3 .. ty0+34 (38 rows = 19 row pairs)
 #define BL_PAIRS (BL_SH / 2)
+#define BL_GROUPS (BL_W / 4)    // 4-pixel groups per row
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -41,19 +43,21 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 
 // Separable fixed-point filter: horizontal sums fit 16 bits (kernel sum <= 257), the vertical pass
 // rounds with +32768 and shifts by 16; variant 1 (kernel sum 257) saturates to 255.
-// Horizontal pass: a thread takes 4 pixels of two rows; each sum is two 4-byte dot products on byte
+// Horizontal pass: a work item is 4 pixels of two rows; each sum is two 4-byte dot products on byte
 // windows cut from three staged words; the two rows' sums of a column share one LDS word.
-// Vertical pass: a thread takes 4 pixels of one row; its 7 taps are four 2 x u16 dot products on
-// those row-pair words (the pairing decides where the zero tap sits).
+// Vertical pass: a thread takes 4 pixels of four rows; the 7 taps of a pixel are four 2 x u16 dot
+// products on those row-pair words (the row's parity decides where the zero tap sits).
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, BlurArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t img[BL_SH * BL_SW];
+    __shared__ __attribute__((aligned(16))) uint32_t img[BL_SH * BL_SWORDS];
     __shared__ __attribute__((aligned(16))) uint32_t hs[BL_PAIRS * BL_W];  // h(row 2p, x) | h(row 2p+1, x) << 16
-    const int f = blockIdx.y;
+    const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
+    if (f >= a.batch)
+        return;
     int lvl = 0;
-    while (lvl + 1 < a.nlevels && (int)blockIdx.x >= a.tile_base[lvl + 1])
+    while (lvl + 1 < a.nlevels && unit >= a.tile_base[lvl + 1])
         lvl++;
-    const int t = blockIdx.x - a.tile_base[lvl];
+    const int t = unit - a.tile_base[lvl];
     const int tx0 = (t % a.tiles_x[lvl]) * BL_W, ty0 = (t / a.tiles_x[lvl]) * BL_H;
     const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
     const int spitch = lvl == 0 ? a.l0.pitch : pitch;
@@ -63,92 +67,107 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const uint32_t kA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);  // taps 0..3
     const uint32_t kB = k2 | (k1 << 8) | (k0 << 16);               // taps 4..6
 
-    const bool interior = tx0 >= 4 && tx0 + BL_W + 4 <= w && ty0 >= 3 && ty0 + BL_H + 3 <= h;
+    // interior: every needed pixel (3 around the tile) exists and whole 16-byte pieces can be read
+    const bool interior = tx0 >= BL_LEFT && tx0 + BL_W + 3 <= w && tx0 + BL_W + 16 <= spitch && ty0 >= 3 &&
+                          ty0 + BL_H + 3 <= h && (spitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
     if (interior) {
-        int r = threadIdx.x / (BL_SW / 4), c4 = threadIdx.x % (BL_SW / 4);
-        for (int i = threadIdx.x; i < BL_SH * (BL_SW / 4); i += 256) {
-            reinterpret_cast<uint32_t *>(img)[i] =
-                *reinterpret_cast<const uint32_t *>(src + (size_t)(ty0 - 3 + r) * spitch + tx0 - 4 + c4 * 4);
-            r += 14, c4 += 4;  // 256 = 14*18 + 4
-            if (c4 >= BL_SW / 4)
-                c4 -= BL_SW / 4, r++;
+        const uint8_t *s0 = src + (size_t)(ty0 - 3) * spitch + (tx0 - BL_LEFT);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = threadIdx.x + 256 * k;  // 38 rows x 10 pieces = 380 items
+            if (i < BL_SH * (BL_SWORDS / 4)) {
+                const int r = i / (BL_SWORDS / 4), c = i % (BL_SWORDS / 4);
+                *reinterpret_cast<uint4 *>(&img[r * BL_SWORDS + 4 * c]) =
+                    *reinterpret_cast<const uint4 *>(s0 + (size_t)r * spitch + 16 * c);
+            }
         }
     } else {
         // edge tile: rows and columns outside the image mirror about the border pixel (reflect 101);
-        // words that lie inside the row are still loaded whole
-        for (int i = threadIdx.x; i < BL_SH * (BL_SW / 4); i += 256) {
-            const int r = i / (BL_SW / 4), c4 = i % (BL_SW / 4);
+        // words that lie inside the row are still loaded whole.  Only words 3 .. 36 of a staged row
+        // (columns tx0-4 .. tx0+131) are needed.
+        for (int i = threadIdx.x; i < BL_SH * 34; i += 256) {
+            const int r = i / 34, c4 = i % 34;
             const int y = reflect101(ty0 - 3 + r, h), x0 = tx0 - 4 + c4 * 4;
             const uint8_t *row = src + (size_t)y * spitch;
             uint32_t v;
             if (x0 >= 0 && x0 + 3 < w)
                 v = *reinterpret_cast<const uint32_t *>(row + x0);
+            else if (x0 - 3 >= w + 3)
+                v = 0;  // right of every needed column
             else
                 v = (uint32_t)row[reflect101(x0, w)] | ((uint32_t)row[reflect101(x0 + 1, w)] << 8) |
                     ((uint32_t)row[reflect101(x0 + 2, w)] << 16) | ((uint32_t)row[reflect101(x0 + 3, w)] << 24);
-            reinterpret_cast<uint32_t *>(img)[i] = v;
+            img[r * BL_SWORDS + 3 + c4] = v;
         }
     }
     __syncthreads();
-    if (threadIdx.x < BL_PAIRS * (BL_W / 4)) {
-        const int p = threadIdx.x >> 4, cg = threadIdx.x & 15;
-        uint32_t hv[2][4];
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            // staged bytes 4cg .. 4cg+11 hold columns x-4 .. x+7 of the group's first pixel x
-            const uint32_t *wp = reinterpret_cast<const uint32_t *>(&img[(2 * p + rr) * BL_SW + cg * 4]);
-            const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+    for (int k = 0; k < 3; k++) {
+        const int item = threadIdx.x + 256 * k;  // 19 row pairs x 32 groups = 608 items
+        if (item < BL_PAIRS * BL_GROUPS) {
+            const int p = item >> 5, cg = item & 31;
+            uint32_t hv[2][4];
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                // pixel x+o: taps at staged bytes o+1 .. o+7
-                const uint32_t lo = o == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, o + 1);  // bytes o+1..o+4
-                const uint32_t hi = o == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, o + 1);  // bytes o+5..o+8
-                hv[rr][o] = __builtin_amdgcn_udot4(hi, kB, __builtin_amdgcn_udot4(lo, kA, 0u, false), false);
+            for (int rr = 0; rr < 2; rr++) {
+                // staged words cg+3 .. cg+5 hold columns x-4 .. x+7 of the group's first pixel x
+                const uint32_t *wp = &img[(2 * p + rr) * BL_SWORDS + cg + 3];
+                const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
+#pragma unroll
+                for (int o = 0; o < 4; o++) {
+                    // pixel x+o: taps at bytes o+1 .. o+7 of the three words
+                    const uint32_t lo = o == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, o + 1);  // bytes o+1..o+4
+                    const uint32_t hi = o == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, o + 1);  // bytes o+5..o+8
+                    hv[rr][o] = __builtin_amdgcn_udot4(hi, kB, __builtin_amdgcn_udot4(lo, kA, 0u, false), false);
+                }
             }
+            uint4 pk;
+            pk.x = hv[0][0] | (hv[1][0] << 16);
+            pk.y = hv[0][1] | (hv[1][1] << 16);
+            pk.z = hv[0][2] | (hv[1][2] << 16);
+            pk.w = hv[0][3] | (hv[1][3] << 16);
+            *reinterpret_cast<uint4 *>(&hs[p * BL_W + cg * 4]) = pk;
         }
-        uint4 pk;
-        pk.x = hv[0][0] | (hv[1][0] << 16);
-        pk.y = hv[0][1] | (hv[1][1] << 16);
-        pk.z = hv[0][2] | (hv[1][2] << 16);
-        pk.w = hv[0][3] | (hv[1][3] << 16);
-        *reinterpret_cast<uint4 *>(&hs[p * BL_W + cg * 4]) = pk;
     }
     __syncthreads();
-    const int r = threadIdx.x >> 4, c0 = (threadIdx.x & 15) * 4;
-    const int y = ty0 + r;
-    if (y < h && tx0 + c0 < pitch) {
-        // output row r sums staged rows r .. r+6 with taps k0 k1 k2 k3 k2 k1 k0
-        const bool odd = r & 1;
-        const int p0 = r >> 1;  // first row pair touched
-        // even r: (k0,k1) (k2,k3) (k2,k1) (k0,0); odd r: (0,k0) (k1,k2) (k3,k2) (k1,k0); low half = even row
-        const uint32_t c01 = odd ? (k0 << 16) : (k0 | (k1 << 16));
-        const uint32_t c23 = odd ? (k1 | (k2 << 16)) : (k2 | (k3 << 16));
-        const uint32_t c45 = odd ? (k3 | (k2 << 16)) : (k2 | (k1 << 16));
-        const uint32_t c67 = odd ? (k1 | (k0 << 16)) : k0;
-        const uint4 q0 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 0) * BL_W + c0]);
-        const uint4 q1 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 1) * BL_W + c0]);
-        const uint4 q2 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 2) * BL_W + c0]);
-        const uint4 q3 = *reinterpret_cast<const uint4 *>(&hs[(p0 + 3) * BL_W + c0]);
-        uint32_t acc[4];
-        acc[0] = dot2_u16(q3.x, c67, dot2_u16(q2.x, c45, dot2_u16(q1.x, c23, dot2_u16(q0.x, c01, 32768u))));
-        acc[1] = dot2_u16(q3.y, c67, dot2_u16(q2.y, c45, dot2_u16(q1.y, c23, dot2_u16(q0.y, c01, 32768u))));
-        acc[2] = dot2_u16(q3.z, c67, dot2_u16(q2.z, c45, dot2_u16(q1.z, c23, dot2_u16(q0.z, c01, 32768u))));
-        acc[3] = dot2_u16(q3.w, c67, dot2_u16(q2.w, c45, dot2_u16(q1.w, c23, dot2_u16(q0.w, c01, 32768u))));
-        uint32_t out = 0;
+    const int cg = threadIdx.x & 31, rb = threadIdx.x >> 5;  // rows 4rb .. 4rb+3 of the tile
+    const int x = tx0 + cg * 4;
+    if (ty0 + 4 * rb < h && x < pitch) {
+        // output row r sums staged rows r .. r+6 with taps k0 k1 k2 k3 k2 k1 k0; a word of hs holds an
+        // even staged row in its low half and the next (odd) row in its high half
+        const uint32_t e01 = k0 | (k1 << 16), e23 = k2 | (k3 << 16), e45 = k2 | (k1 << 16), e67 = k0;
+        const uint32_t o01 = k0 << 16, o23 = k1 | (k2 << 16), o45 = k3 | (k2 << 16), o67 = k1 | (k0 << 16);
+        uint4 q[5];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            uint32_t v = acc[i] >> 16;
-            v = v > 255u ? 255u : v;
-            out |= v << (8 * i);
+        for (int j = 0; j < 5; j++)
+            q[j] = *reinterpret_cast<const uint4 *>(&hs[(2 * rb + j) * BL_W + cg * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int y = ty0 + 4 * rb + j;
+            if (y >= h)
+                break;
+            const bool odd = j & 1;
+            const int p0 = j >> 1;
+            const uint32_t c01 = odd ? o01 : e01, c23 = odd ? o23 : e23, c45 = odd ? o45 : e45, c67 = odd ? o67 : e67;
+            uint32_t acc[4];
+            acc[0] = dot2_u16(q[p0 + 3].x, c67, dot2_u16(q[p0 + 2].x, c45, dot2_u16(q[p0 + 1].x, c23, dot2_u16(q[p0].x, c01, 32768u))));
+            acc[1] = dot2_u16(q[p0 + 3].y, c67, dot2_u16(q[p0 + 2].y, c45, dot2_u16(q[p0 + 1].y, c23, dot2_u16(q[p0].y, c01, 32768u))));
+            acc[2] = dot2_u16(q[p0 + 3].z, c67, dot2_u16(q[p0 + 2].z, c45, dot2_u16(q[p0 + 1].z, c23, dot2_u16(q[p0].z, c01, 32768u))));
+            acc[3] = dot2_u16(q[p0 + 3].w, c67, dot2_u16(q[p0 + 2].w, c45, dot2_u16(q[p0 + 1].w, c23, dot2_u16(q[p0].w, c01, 32768u))));
+            // byte 2 of each sum is the result; a sum of 2^24 (variant 1 only) saturates to 255
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                acc[i] = min(acc[i], 0x00ffffffu);
+            const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);  // bytes: acc0.b2, acc1.b2
+            const uint32_t hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);  // upper half: acc2.b2, acc3.b2
+            *reinterpret_cast<uint32_t *>(dst + (size_t)y * pitch + x) = lo | hi;
         }
-        *reinterpret_cast<uint32_t *>(dst + (size_t)y * pitch + tx0 + c0) = out;
     }
 }
 
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
 {
     BlurArgs a;
-    a.nlevels = g.nlevels, a.slab = g.slab, a.variant = g.blur_variant;
+    a.nlevels = g.nlevels, a.slab = g.slab, a.variant = g.blur_variant, a.batch = g.batch;
     a.l0 = b.l0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
@@ -156,7 +175,7 @@ hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
         a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
     }
     a.tile_base[g.nlevels] = g.tiles_per_frame;
-    k_blur<<<dim3(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, a);
+    k_blur<<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, a);
     return hipGetLastError();
 }
 
@@ -196,7 +215,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 struct DescArgs {
-    int nlevels, slab, kp_per_frame, out_cap;
+    int nlevels, slab, kp_per_frame, out_cap, batch;
     OrbxLevel0 l0;
     int pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], kp_base[ORBX_MAX_LEVELS], patch_size[ORBX_MAX_LEVELS];
     float scale[ORBX_MAX_LEVELS];
@@ -230,7 +249,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ int s_upitch[DESC_SLOTS];                    // row pitch of the unblurred level
     __shared__ long long s_usrc[DESC_SLOTS];                // byte offset of the unblurred level from pyr
     __shared__ float s_scale[DESC_SLOTS], s_size[DESC_SLOTS], s_resp[DESC_SLOTS];
-    const int f = blockIdx.y;
+    const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
+    if (f >= a.batch)
+        return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
         int acc = 0;
@@ -239,12 +260,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             acc += nkept[f * a.nlevels + l];
         }
         s_first[a.nlevels] = acc;
-        if (blockIdx.x == 0)
+        if (unit == 0)
             out_n[f] = acc;
     }
     __syncthreads();
     const int total = s_first[a.nlevels];
-    const int base = blockIdx.x * DESC_SLOTS;
+    const int base = unit * DESC_SLOTS;
     if (base >= total)
         return;
     uint32_t *win = s_win[wv];
@@ -425,13 +446,14 @@ hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStre
 {
     DescArgs a;
     a.nlevels = g.nlevels, a.slab = g.slab, a.kp_per_frame = g.kp_per_frame, a.out_cap = g.out_cap;
+    a.batch = g.batch;
     a.l0 = b.l0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.pitch[l] = L.pitch, a.off[l] = L.off, a.kp_base[l] = L.kp_base, a.patch_size[l] = L.patch_size;
         a.scale[l] = L.scale;
     }
-    dim3 grid((g.out_cap + DESC_SLOTS - 1) / DESC_SLOTS, g.batch);
+    const dim3 grid = orbx_frame_grid((g.out_cap + DESC_SLOTS - 1) / DESC_SLOTS, g.batch);
     k_describe<<<grid, 256, 0, s>>>(b.pyr, b.blur, b.kept_xy, b.kept_resp, b.nkept, b.out_kp, b.out_desc, b.out_n, a);
     return hipGetLastError();
 }

@@ -111,7 +111,7 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
 }
 
 struct FastArgs {
-    int nlevels, slab, cells_per_frame, cand_per_frame, tiles_per_frame;
+    int nlevels, slab, cells_per_frame, cand_per_frame, tiles_per_frame, batch;
     OrbxLevel0 l0;
     int t_low, t_ini;  // min(iniThFAST, minThFAST) and iniThFAST, clamped to [1,255]
     int tile_base[ORBX_MAX_LEVELS + 1];
@@ -130,18 +130,20 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     __shared__ uint16_t queue[SC_H * SC_W];  // pixels that passed the compass test: staged row<<7 | staged column
     __shared__ int qn, sn;
 
-    const int f = blockIdx.y;
+    const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
+    if (f >= a.batch)
+        return;
     int lvl = 0;
-    while (lvl + 1 < a.nlevels && (int)blockIdx.x >= a.tile_base[lvl + 1])
+    while (lvl + 1 < a.nlevels && unit >= a.tile_base[lvl + 1])
         lvl++;
-    const int t = blockIdx.x - a.tile_base[lvl];
+    const int t = unit - a.tile_base[lvl];
     const int tx0 = (t % a.tiles_x[lvl]) * ORBX_FAST_W;
     const int ty0 = (t / a.tiles_x[lvl]) * ORBX_FAST_H;
     const int w = a.w[lvl], h = a.h[lvl], pitch = lvl == 0 ? a.l0.pitch : a.pitch[lvl];
     const int wc = a.wcell[lvl], hc = a.hcell[lvl];
     const int x_lo = ORBX_CELL_ORG, x_hi = w - ORBX_CELL_ORG, y_lo = ORBX_CELL_ORG, y_hi = h - ORBX_CELL_ORG;
     // tiles that hold no detectable pixel, and levels without a cell grid, produce nothing
-    int *my_cnt = tile_cnt + (size_t)f * a.tiles_per_frame + blockIdx.x;
+    int *my_cnt = tile_cnt + (size_t)f * a.tiles_per_frame + unit;
     if (wc == 0 || tx0 + ORBX_FAST_W <= x_lo || tx0 >= x_hi || ty0 + ORBX_FAST_H <= y_lo || ty0 >= y_hi) {
         if (threadIdx.x == 0)
             *my_cnt = 0;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
 
     // ---- non-maximum suppression inside the pixel's cell, on the tile proper ----
     // Survivors go to the tile's own list (no global atomics); a later pass concatenates the lists.
-    uint2 *my_list = tile_list + ((size_t)f * a.tiles_per_frame + blockIdx.x) * ORBX_TILE_CAP;
+    uint2 *my_list = tile_list + ((size_t)f * a.tiles_per_frame + unit) * ORBX_TILE_CAP;
     uint8_t *flags = cell_flag + (size_t)f * a.cells_per_frame + a.cell_base[lvl];
     for (int qi = threadIdx.x; qi < nq; qi += 256) {
         const int e = queue[qi];
@@ -282,12 +284,14 @@ __global__ __launch_bounds__(64) void k_gather(const int *__restrict__ tile_cnt,
                                                uint8_t *__restrict__ cand_resp, uint32_t *__restrict__ cand_key,
                                                int *__restrict__ status, FastArgs a)
 {
-    const int f = blockIdx.y;
+    const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
+    if (f >= a.batch)
+        return;
     int lvl = 0;
-    while (lvl + 1 < a.nlevels && (int)blockIdx.x >= a.tile_base[lvl + 1])
+    while (lvl + 1 < a.nlevels && unit >= a.tile_base[lvl + 1])
         lvl++;
     const int first = a.tile_base[lvl], ntiles = a.tile_base[lvl + 1] - first;
-    const int me = blockIdx.x - first;
+    const int me = unit - first;
     const int *cnt = tile_cnt + (size_t)f * a.tiles_per_frame + first;
     const int lane = threadIdx.x;
     int before = 0, all = 0;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(64) void k_gather(const int *__restrict__ tile_cnt,
         }
     }
     const int mine = cnt[me];
-    const uint2 *src = tile_list + ((size_t)f * a.tiles_per_frame + blockIdx.x) * ORBX_TILE_CAP;
+    const uint2 *src = tile_list + ((size_t)f * a.tiles_per_frame + unit) * ORBX_TILE_CAP;
     const size_t cb = (size_t)f * a.cand_per_frame + a.cand_base[lvl];
     for (int j = lane; j < mine; j += 64) {
         const int k = before + j;
@@ -328,6 +332,7 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
 {
     FastArgs a;
     a.nlevels = g.nlevels;
+    a.batch = g.batch;
     a.slab = g.slab;
     a.l0 = b.l0;
     a.cells_per_frame = g.cells_per_frame;
@@ -349,7 +354,7 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
     if (part == 0)
         return g.cells_per_frame > 0 ? hipMemsetAsync(b.cell_flag, 0, (size_t)g.batch * g.cells_per_frame, s)
                                      : hipSuccess;
-    dim3 grid(g.ftiles_per_frame, g.batch);
+    const dim3 grid = orbx_frame_grid(g.ftiles_per_frame, g.batch);
     if (part == 1) {
         k_fast<<<grid, 256, 0, s>>>(b.pyr, b.tile_cnt, b.tile_list, b.cell_flag, a);
         return hipGetLastError();

@@ -14,8 +14,8 @@
 #define ORBX_MAX_ROOTS 64   // quadtree roots per level (round(width/height) of the detection region)
 
 // blur tile produced by one workgroup
-#define ORBX_FT_W 64
-#define ORBX_FT_H 16
+#define ORBX_FT_W 128
+#define ORBX_FT_H 32
 // FAST tile produced by one workgroup
 #define ORBX_FAST_W 64
 #define ORBX_FAST_H 64
@@ -97,6 +97,21 @@ struct OrbxBuffers {
 };
 
 // kernel launchers (each enqueues on `s` and returns the hipGetLastError code)
+// Grids of kernels that work on (unit-of-a-frame, frame) pairs are shaped (gx, units, groups) with
+// gx = 8 once the batch has 8 frames: the 8 workgroups dispatched back to back (one to each XCD)
+// then belong to 8 different frames, so every workgroup of a frame runs on the same XCD and the
+// frame's rows are shared through that XCD's L2.  Smaller batches keep gx = 1 (all XCDs work on
+// the same frame).  This is a placement hint only; results do not depend on it.
+static inline dim3 orbx_frame_grid(int units_per_frame, int batch)
+{
+    const int gx = batch >= 8 ? 8 : 1;
+    return dim3(gx, units_per_frame, (batch + gx - 1) / gx);
+}
+#if defined(__HIPCC__)
+#define ORBX_BLOCK_FRAME ((int)(blockIdx.z * gridDim.x + blockIdx.x))  // may be >= batch in the last group
+#define ORBX_BLOCK_UNIT ((int)blockIdx.y)
+#endif
+
 hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, const OrbxGeom &g, const OrbxBuffers &b,
                               hipStream_t s);
 hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
