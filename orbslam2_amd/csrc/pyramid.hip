@@ -39,13 +39,18 @@ hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, c
 // tables built on the host for the current image size (they depend on the column or row only).
 #define RS_ROWS 2  // destination rows per thread
 
+typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
+
 // Each thread produces 4 adjacent pixels of RS_ROWS destination rows.  When the source bytes of the
-// four pixels fit 12 bytes from an aligned word (any scale factor up to 2), each source row costs
-// three word loads and the pixels are picked with byte permutes.
+// four pixels lie within 8 bytes of the first one (any scale factor up to 2), each source row costs
+// one 12-byte load from the aligned word below the first pixel, two byte alignments that bring the
+// first pixel to byte 0, and per pixel one byte permute (the two neighbours as a 2 x u16 vector) and
+// one 2 x u16 dot product with the packed coefficient pair.  Threads whose 12 bytes would end
+// behind `src_bytes` (the readable bytes of a frame) take the byte-wise path.
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_lvl, long long src_fstride,
-                                                uint8_t *__restrict__ pyr_out, int slab, int spitch, int doff,
-                                                int dpitch, int dw, int dh, const OrbxXCoef *__restrict__ xt,
-                                                const OrbxYCoef *__restrict__ yt)
+                                                uint32_t src_bytes, uint8_t *__restrict__ pyr_out, int slab, int spitch,
+                                                int doff, int dpitch, int dw, int dh,
+                                                const OrbxXCoef *__restrict__ xt, const OrbxYCoef *__restrict__ yt)
 {
     const int f = blockIdx.z;
     const int dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS;
@@ -53,64 +58,53 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
     if (dy0 >= dh || dx0 >= dw)
         return;
     // the tables are padded to a multiple of 4 columns / RS_ROWS rows with copies of the last entry
-    OrbxXCoef cx[4];
-    {
-        const uint4 t0 = *reinterpret_cast<const uint4 *>(xt + dx0), t1 = *reinterpret_cast<const uint4 *>(xt + dx0 + 2);
-        cx[0] = OrbxXCoef{(int)t0.x, (short)(t0.y & 0xffff), (short)(t0.y >> 16)};
-        cx[1] = OrbxXCoef{(int)t0.z, (short)(t0.w & 0xffff), (short)(t0.w >> 16)};
-        cx[2] = OrbxXCoef{(int)t1.x, (short)(t1.y & 0xffff), (short)(t1.y >> 16)};
-        cx[3] = OrbxXCoef{(int)t1.z, (short)(t1.w & 0xffff), (short)(t1.w >> 16)};
-    }
-    OrbxYCoef cy[RS_ROWS];
+    const uint4 t0 = *reinterpret_cast<const uint4 *>(xt + dx0), t1 = *reinterpret_cast<const uint4 *>(xt + dx0 + 2);
+    const int sx[4] = {(int)t0.x, (int)t0.z, (int)t1.x, (int)t1.z};
+    const uint32_t coef[4] = {t0.y, t0.w, t1.y, t1.w};  // a0 | a1 << 16
+    uint4 cy[RS_ROWS];  // sy0, sy1, b0, b1
 #pragma unroll
-    for (int r = 0; r < RS_ROWS; r++) {
-        const uint4 t = *reinterpret_cast<const uint4 *>(yt + dy0 + r);
-        cy[r] = OrbxYCoef{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
-    }
+    for (int r = 0; r < RS_ROWS; r++)
+        cy[r] = *reinterpret_cast<const uint4 *>(yt + dy0 + r);
     const uint8_t *sbase = src_lvl + (size_t)f * src_fstride;
     uint8_t *dbase = pyr_out + (size_t)f * slab + doff;
-    const int wb = cx[0].sx & ~3;               // aligned byte offset of the first word
-    const bool wide = cx[3].sx + 1 - wb < 12;   // all needed bytes inside three words
-    int h[RS_ROWS][2][4];
-    if (wide) {
-        uint32_t wds[RS_ROWS][2][3];
+    const uint32_t wb = (uint32_t)sx[0] & ~3u;  // aligned byte offset of the first word
+    const uint32_t s0 = (uint32_t)sx[0] & 3u;
+    const uint32_t last_row = max(max(cy[0].x, cy[0].y), max(cy[1].x, cy[1].y));
+    const bool narrow = sx[3] + 1 - sx[0] <= 7 && last_row * (uint32_t)spitch + wb + 12u <= src_bytes;
+    uint32_t h[RS_ROWS][2][4];
+    if (narrow) {
+        uint32_t sel[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            sel[i] = (uint32_t)(sx[i] - sx[0]) * 0x00010001u + 0x0c010c00u;  // bytes d, 0, d+1, 0
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const uint8_t *row = sbase + (size_t)(k ? cy[r].sy1 : cy[r].sy0) * spitch + wb;
+                const uint32_t off = (k ? cy[r].y : cy[r].x) * (uint32_t)spitch + wb;
+                const uint32_t *row = reinterpret_cast<const uint32_t *>(sbase + off);
+                const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+                const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, s0);  // source bytes sx0 .. sx0+3
+                const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, s0);  // source bytes sx0+4 .. sx0+7
 #pragma unroll
-                for (int j = 0; j < 3; j++)
-                    wds[r][k][j] = wb + 4 * j < spitch ? *reinterpret_cast<const uint32_t *>(row + 4 * j) : 0u;
-            }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int off = cx[i].sx - wb;  // 0..10
-            const bool up = off >= 4;
-            const uint32_t o2 = (uint32_t)(up ? off - 4 : off);       // 0..6 inside the chosen word pair
-            const uint32_t sel = 0x0c0c0000u | ((o2 + 1) << 8) | o2;  // bytes o2, o2+1 -> low two bytes
-            const int c0 = cx[i].a0, c1 = cx[i].a1;
-#pragma unroll
-            for (int r = 0; r < RS_ROWS; r++)
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint32_t lo = up ? wds[r][k][1] : wds[r][k][0];
-                    const uint32_t hi = up ? wds[r][k][2] : wds[r][k][1];
-                    const uint32_t pq = __builtin_amdgcn_perm(hi, lo, sel);
-                    h[r][k][i] = (int)(pq & 0xff) * c0 + (int)(pq >> 8) * c1;
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t pq = __builtin_amdgcn_perm(hi, lo, sel[i]);
+                    h[r][k][i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, pq),
+                                                        __builtin_bit_cast(rs_us2, coef[i]), 0u, false);
                 }
-        }
+            }
     } else {
 #pragma unroll
         for (int r = 0; r < RS_ROWS; r++)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const uint8_t *row = sbase + (size_t)(k ? cy[r].sy1 : cy[r].sy0) * spitch;
+                const uint8_t *row = sbase + (size_t)(k ? cy[r].y : cy[r].x) * spitch;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     // a1 == 0 marks columns whose right neighbour must not be read
-                    const int s1 = cx[i].a1 ? cx[i].sx + 1 : cx[i].sx;
-                    h[r][k][i] = row[cx[i].sx] * cx[i].a0 + row[s1] * cx[i].a1;
+                    const uint32_t a0 = coef[i] & 0xffffu, a1 = coef[i] >> 16;
+                    const int s1 = a1 ? sx[i] + 1 : sx[i];
+                    h[r][k][i] = row[sx[i]] * a0 + row[s1] * a1;
                 }
             }
     }
@@ -121,9 +115,9 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
         uint32_t out = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int v = (((cy[r].b0 * (h[r][0][i] >> 4)) >> 16) + ((cy[r].b1 * (h[r][1][i] >> 4)) >> 16) + 2) >> 2;
-            if (dx0 + i < dw)
-                out |= (uint32_t)(v & 0xff) << (8 * i);
+            // both products stay below 2^27: 24-bit multiplies are exact
+            const uint32_t v = ((__umul24(cy[r].z, h[r][0][i] >> 4) >> 16) + (__umul24(cy[r].w, h[r][1][i] >> 4) >> 16) + 2u) >> 2;
+            out |= v << (8 * i);
         }
         *reinterpret_cast<uint32_t *>(dbase + (size_t)(dy0 + r) * dpitch + dx0) = out;
     }
@@ -137,7 +131,10 @@ hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b
     const uint8_t *src = level == 1 ? b.l0.ptr : b.pyr + S.off;
     const long long sfs = level == 1 ? b.l0.fstride : (long long)g.slab;
     const int spitch = level == 1 ? b.l0.pitch : S.pitch;
-    k_resize<<<grid, 256, 0, s>>>(src, sfs, b.pyr, g.slab, spitch, D.off, D.pitch, D.w, D.h, b.xtab + D.xtab_off,
-                                  b.ytab + D.ytab_off);
+    // a frame's own rows at level 0 (the caller's buffer ends there); lower levels sit inside the slab,
+    // which has slack behind its last level
+    const uint32_t src_bytes = (uint32_t)spitch * (uint32_t)S.h + (level == 1 ? 0u : 16u);
+    k_resize<<<grid, 256, 0, s>>>(src, sfs, src_bytes, b.pyr, g.slab, spitch, D.off, D.pitch, D.w, D.h,
+                                  b.xtab + D.xtab_off, b.ytab + D.ytab_off);
     return hipGetLastError();
 }
