@@ -20,11 +20,15 @@
 // polarities at once with packed 16-bit min/max; suppress non-maxima; append.
 #include "orbx_internal.h"
 
-#define IMG_W (ORBX_FAST_W + 8)  // 72 staged columns: tx0-4 .. tx0+67
-#define IMG_H (ORBX_FAST_H + 8)  // 72 staged rows:    ty0-4 .. ty0+67
-#define SC_W (ORBX_FAST_W + 2)   // 66: tile plus a one-pixel ring (staged columns 3..68)
+#define IMG_W 96                 // staged bytes per row: columns tx0-16 .. tx0+79 (16-byte pieces)
+#define IMG_X0 16                // staged column of pixel tx0
+#define IMG_H (ORBX_FAST_H + 8)  // 72 staged rows: ty0-4 .. ty0+67
+#define IMG_WORDS (IMG_W / 4)    // 24 words per staged row
+#define GRP_0 3                  // first word of a row that matters: columns tx0-4 .. tx0-1
+#define GRP_W 18                 // words that matter: columns tx0-4 .. tx0+67
+#define SC_W (ORBX_FAST_W + 2)   // 66: tile plus a one-pixel ring
 #define SC_H (ORBX_FAST_H + 2)   // 66: staged rows 3..68
-#define GRP_W (IMG_W / 4)        // 18 four-pixel groups per staged row
+#define QUEUE_CAP (SC_H * SC_W)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
@@ -50,8 +54,8 @@ __device__ __forceinline__ uint32_t widen_hi(uint32_t w) { return __builtin_amdg
 
 // Compass test of two pixels at once (u16 halves).  A 9-arc holds at least one pixel of each
 // antipodal pair, so a corner at threshold t needs  max(min(r0,r8), min(r4,r12)) < v-t  (dark arc)
-// or  min(max(r0,r8), max(r4,r12)) > v+t  (bright arc).  Returns sign bits (0x8000 per half) set
-// where the test passes; tt = t | t<<16.
+// or  min(max(r0,r8), max(r4,r12)) > v+t  (bright arc).  The sign bit of each half of the result is
+// set where the test passes (the other bits are noise); tt = t | t<<16.
 __device__ __forceinline__ uint32_t compass2(uint32_t v, uint32_t r0, uint32_t r8, uint32_t r4, uint32_t r12,
                                              uint32_t tt)
 {
@@ -60,7 +64,7 @@ __device__ __forceinline__ uint32_t compass2(uint32_t v, uint32_t r0, uint32_t r
     // dark: dk + t - v < 0 ; bright: v + t - br < 0   (all values < 512: no 16-bit overflow)
     const uint32_t a = pk_sub(dk + tt, v);
     const uint32_t b = pk_sub(v + tt, br);
-    return (a | b) & 0x80008000u;
+    return a | b;
 }
 
 // t points at the centre byte of the staged tile.  Ring bytes are widened to p | (255-p)<<16:
@@ -88,9 +92,10 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
     d[13] = t[p - 3];
     d[14] = t[2 * p - 2];
     d[15] = t[3 * p - 1];
+    // p -> p | (255-p) << 16 in one 24-bit multiply-add: p * (1 - 65536) + (255 << 16)
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        d[k] = (d[k] * 0x10001u) ^ 0x00ff0000u;
+        d[k] = (uint32_t)(__mul24((int)d[k], -65535) + 0x00ff0000);
     uint32_t m2[16], m4[16];
 #pragma unroll
     for (int k = 0; k < 16; k++)
@@ -119,7 +124,13 @@ struct FastArgs {
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
     int wcell[ORBX_MAX_LEVELS], hcell[ORBX_MAX_LEVELS], ncols[ORBX_MAX_LEVELS], cell_base[ORBX_MAX_LEVELS];
     int cand_base[ORBX_MAX_LEVELS], cand_cap[ORBX_MAX_LEVELS];
+    uint32_t wc_magic[ORBX_MAX_LEVELS], hc_magic[ORBX_MAX_LEVELS];  // ceil(2^20 / cell size)
 };
+
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, int *__restrict__ tile_cnt,
                                               uint2 *__restrict__ tile_list, uint8_t *__restrict__ cell_flag,
@@ -127,8 +138,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[IMG_H * IMG_W];  // staged pixels
     __shared__ __attribute__((aligned(16))) uint8_t sc[IMG_H * IMG_W];   // A where it exceeds t_low, else 0 (staged coordinates)
-    __shared__ uint16_t queue[SC_H * SC_W];  // pixels that passed the compass test: staged row<<7 | staged column
-    __shared__ int qn, sn;
+    __shared__ uint16_t queue[QUEUE_CAP + 64];  // pixels that passed the compass test: staged row<<7 | staged column
+    __shared__ int qn, sn;                      // (the last 64 entries take the stores of lanes with nothing to queue)
 
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
@@ -150,23 +161,37 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         return;
     }
     const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
+    const int lane = threadIdx.x & 63;
+    uint32_t *img32 = reinterpret_cast<uint32_t *>(img);
+    uint32_t *sc32 = reinterpret_cast<uint32_t *>(sc);
 
     if (threadIdx.x == 0)
         qn = 0, sn = 0;
-    // stage rows ty0-4 .. ty0+67, columns tx0-4 .. tx0+67 (word aligned: tx0 is a multiple of 64)
-    const bool inside = tx0 >= 4 && tx0 + ORBX_FAST_W + 4 <= pitch && ty0 >= 4 && ty0 + ORBX_FAST_H + 4 <= h;
-    {
-        // 256 = 14*18 + 4: the (row, group) of a thread's next word follows without a division
-        int r = threadIdx.x / GRP_W, c4 = threadIdx.x % GRP_W;
-        for (int i = threadIdx.x; i < IMG_H * GRP_W; i += 256) {
-            const int y = ty0 - 4 + r, x = tx0 - 4 + c4 * 4;
+    // a thread keeps one word column (of the 18 that matter) and walks down the rows in steps of 14
+    const int g = threadIdx.x % GRP_W, r0 = threadIdx.x / GRP_W;
+    const bool walker = threadIdx.x < 14 * GRP_W;
+    // stage rows ty0-4 .. ty0+67; whole 16-byte pieces where the tile lies inside the level
+    const bool inside = tx0 >= IMG_X0 && tx0 + IMG_W - IMG_X0 <= pitch && ty0 >= 4 && ty0 + ORBX_FAST_H + 4 <= h &&
+                        (pitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
+    if (inside) {
+        const uint8_t *s0 = src + (size_t)(ty0 - 4) * pitch + (tx0 - IMG_X0);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = threadIdx.x + 256 * k;  // 72 rows x 6 pieces = 432 items
+            if (i < IMG_H * (IMG_W / 16)) {
+                const int r = i / (IMG_W / 16), c = i % (IMG_W / 16);
+                *reinterpret_cast<uint4 *>(&img[r * IMG_W + 16 * c]) =
+                    *reinterpret_cast<const uint4 *>(s0 + (size_t)r * pitch + 16 * c);
+            }
+        }
+    } else if (walker) {
+        const int x = tx0 - 4 + 4 * g;
+        for (int r = r0; r < IMG_H; r += 14) {
+            const int y = ty0 - 4 + r;
             uint32_t v = 0;
-            if (inside || (y >= 0 && y < h && x >= 0 && x < pitch))
+            if (y >= 0 && y < h && x >= 0 && x < pitch)
                 v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * pitch + x);
-            reinterpret_cast<uint32_t *>(img)[i] = v;
-            r += 14, c4 += 4;
-            if (c4 >= GRP_W)
-                c4 -= GRP_W, r++;
+            img32[r * IMG_WORDS + GRP_0 + g] = v;
         }
     }
     __syncthreads();
@@ -178,43 +203,53 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     const bool all_valid = tx0 - 1 >= x_lo && tx0 + ORBX_FAST_W + 1 <= x_hi && ty0 - 1 >= y_lo &&
                            ty0 + ORBX_FAST_H + 1 <= y_hi;
     {
-        int r = threadIdx.x / GRP_W + 3, g = threadIdx.x % GRP_W;
-        for (int i = threadIdx.x; i < SC_H * GRP_W; i += 256) {
-            reinterpret_cast<uint32_t *>(sc)[r * GRP_W + g] = 0u;
-            const int y = ty0 - 4 + r, xg = tx0 - 4 + 4 * g;
-            if (all_valid || (y >= y_lo && y < y_hi && xg + 3 >= x_lo && xg < x_hi)) {
-                const uint32_t *wrow = reinterpret_cast<const uint32_t *>(img) + r * GRP_W + g;
-                const uint32_t vw = wrow[0], upw = wrow[-3 * GRP_W], dnw = wrow[3 * GRP_W];
-                const uint32_t lw = g > 0 ? wrow[-1] : 0u, rw = g < GRP_W - 1 ? wrow[1] : 0u;
-                const uint32_t r4w = __builtin_amdgcn_alignbyte(rw, vw, 3);   // pixels x+3
-                const uint32_t r12w = __builtin_amdgcn_alignbyte(vw, lw, 1);  // pixels x-3
-                const uint32_t m0 = compass2(widen_lo(vw), widen_lo(dnw), widen_lo(upw), widen_lo(r4w),
-                                             widen_lo(r12w), tt);
-                const uint32_t m1 = compass2(widen_hi(vw), widen_hi(dnw), widen_hi(upw), widen_hi(r4w),
-                                             widen_hi(r12w), tt);
-                uint32_t pass = ((m0 >> 15) & 1u) | ((m0 >> 30) & 2u) | ((m1 >> 13) & 4u) | ((m1 >> 28) & 8u);
-                // the groups left and right of the tile hold one needed pixel each
-                if (g == 0)
-                    pass &= 8u;
-                if (g == GRP_W - 1)
-                    pass &= 1u;
-                if (!all_valid) {
+        // bit 7 of byte o of a pass word stands for pixel o of the group; the groups left and right
+        // of the tile hold one needed pixel each
+        const int xg = tx0 - 4 + 4 * g;
+        uint32_t gmask = !walker ? 0u : g == 0 ? 0x80000000u : g == GRP_W - 1 ? 0x00000080u : 0x80808080u;
+        if (!all_valid) {
 #pragma unroll
-                    for (int o = 0; o < 4; o++)
-                        if (xg + o < x_lo || xg + o >= x_hi)
-                            pass &= ~(1u << o);
-                }
-                if (pass) {
-                    int k = atomicAdd(&qn, __popc(pass));
-#pragma unroll
-                    for (int o = 0; o < 4; o++)
-                        if (pass & (1u << o))
-                            queue[k++] = (uint16_t)((r << 7) | (4 * g + o));
+            for (int o = 0; o < 4; o++)
+                if (xg + o < x_lo || xg + o >= x_hi)
+                    gmask &= ~(0x80u << (8 * o));
+        }
+        for (int k = 0; k < 5; k++) {  // every lane of the wave makes every trip: the ballots below need that
+            const int r = r0 + 3 + 14 * k;
+            const int y = ty0 - 4 + r;
+            uint32_t pass = 0;
+            if (walker && r < 3 + SC_H) {
+                const uint32_t *wrow = img32 + r * IMG_WORDS + GRP_0 + g;
+                sc32[r * IMG_WORDS + GRP_0 + g] = 0u;
+                if (gmask != 0u && (all_valid || (y >= y_lo && y < y_hi))) {
+                    const uint32_t vw = wrow[0], upw = wrow[-3 * IMG_WORDS], dnw = wrow[3 * IMG_WORDS];
+                    const uint32_t lw = wrow[-1], rw = wrow[1];
+                    const uint32_t r4w = __builtin_amdgcn_alignbyte(rw, vw, 3);   // pixels x+3
+                    const uint32_t r12w = __builtin_amdgcn_alignbyte(vw, lw, 1);  // pixels x-3
+                    const uint32_t m0 = compass2(widen_lo(vw), widen_lo(dnw), widen_lo(upw), widen_lo(r4w),
+                                                 widen_lo(r12w), tt);
+                    const uint32_t m1 = compass2(widen_hi(vw), widen_hi(dnw), widen_hi(upw), widen_hi(r4w),
+                                                 widen_hi(r12w), tt);
+                    // sign bytes of the four halves, in pixel order
+                    pass = __builtin_amdgcn_perm(m1, m0, 0x07050301u) & gmask;
                 }
             }
-            r += 14, g += 4;
-            if (g >= GRP_W)
-                g -= GRP_W, r++;
+            // queue slots: bit o of all lanes first, lanes in order (any one-to-one assignment would do)
+            const unsigned long long b0 = __ballot(pass & 0x80u), b1 = __ballot(pass & 0x8000u);
+            const unsigned long long b2 = __ballot(pass & 0x800000u), b3 = __ballot(pass & 0x80000000u);
+            const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+            const int total = n0 + n1 + n2 + n3;
+            if (total) {
+                int base = 0;
+                if (lane == 0)
+                    base = atomicAdd(&qn, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t e = (uint32_t)(r << 7) | (uint32_t)(4 * (GRP_0 + g));
+                const int dump = QUEUE_CAP + lane;
+                queue[(pass & 0x80u) ? base + lanes_below(b0) : dump] = (uint16_t)e;
+                queue[(pass & 0x8000u) ? base + n0 + lanes_below(b1) : dump] = (uint16_t)(e + 1);
+                queue[(pass & 0x800000u) ? base + n0 + n1 + lanes_below(b2) : dump] = (uint16_t)(e + 2);
+                queue[(pass & 0x80000000u) ? base + n0 + n1 + n2 + lanes_below(b3) : dump] = (uint16_t)(e + 3);
+            }
         }
     }
     __syncthreads();
@@ -234,33 +269,27 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     // Survivors go to the tile's own list (no global atomics); a later pass concatenates the lists.
     uint2 *my_list = tile_list + ((size_t)f * a.tiles_per_frame + unit) * ORBX_TILE_CAP;
     uint8_t *flags = cell_flag + (size_t)f * a.cells_per_frame + a.cell_base[lvl];
+    const uint32_t wc_magic = a.wc_magic[lvl], hc_magic = a.hc_magic[lvl];
     for (int qi = threadIdx.x; qi < nq; qi += 256) {
         const int e = queue[qi];
         const int r = e >> 7, c = e & 127;
-        if (r < 4 || r >= 4 + ORBX_FAST_H || c < 4 || c >= 4 + ORBX_FAST_W)
-            continue;  // ring pixel: belongs to a neighbouring tile
         const uint8_t *p = &sc[r * IMG_W + c];
         const int A = p[0];
-        if (A == 0)
+        // ring pixels belong to a neighbouring tile
+        if (A == 0 || r < 4 || r >= 4 + ORBX_FAST_H || c < IMG_X0 || c >= IMG_X0 + ORBX_FAST_W)
             continue;
-        const int y = ty0 - 4 + r, x = tx0 - 4 + c;
-        const int cj = (x - ORBX_CELL_ORG) / wc, ci = (y - ORBX_CELL_ORG) / hc;
+        const int y = ty0 - 4 + r, x = tx0 - IMG_X0 + c;
+        // x - 19 < 4096 and cells are 30 .. 60 pixels: the 20-bit reciprocal divides exactly
+        const int cj = (int)(((uint32_t)(x - ORBX_CELL_ORG) * wc_magic) >> 20);
+        const int ci = (int)(((uint32_t)(y - ORBX_CELL_ORG) * hc_magic) >> 20);
         const int cx0 = ORBX_CELL_ORG + cj * wc, cy0 = ORBX_CELL_ORG + ci * hc;
         const bool l = x - 1 >= cx0, rr = x + 1 < cx0 + wc;
         const bool u = y - 1 >= cy0, dn = y + 1 < cy0 + hc;
-        int m = 0;
-        if (l) m = max(m, (int)p[-1]);
-        if (rr) m = max(m, (int)p[1]);
-        if (u) {
-            m = max(m, (int)p[-IMG_W]);
-            if (l) m = max(m, (int)p[-IMG_W - 1]);
-            if (rr) m = max(m, (int)p[-IMG_W + 1]);
-        }
-        if (dn) {
-            m = max(m, (int)p[IMG_W]);
-            if (l) m = max(m, (int)p[IMG_W - 1]);
-            if (rr) m = max(m, (int)p[IMG_W + 1]);
-        }
+        const int nl = l ? p[-1] : 0, nr = rr ? p[1] : 0;
+        const int ul = l ? p[-IMG_W - 1] : 0, uc = p[-IMG_W], ur = rr ? p[-IMG_W + 1] : 0;
+        const int dl = l ? p[IMG_W - 1] : 0, dc = p[IMG_W], dr = rr ? p[IMG_W + 1] : 0;
+        const int mu = u ? max(max(ul, uc), ur) : 0, md = dn ? max(max(dl, dc), dr) : 0;
+        const int m = max(max(nl, nr), max(mu, md));
         if (A > m) {
             const int cell = ci * a.ncols[lvl] + cj;
             const int k = atomicAdd(&sn, 1);  // LDS; at most ORBX_TILE_CAP strict per-cell maxima fit a tile
@@ -349,6 +378,8 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
         a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
         a.wcell[l] = L.wcell, a.hcell[l] = L.hcell, a.ncols[l] = L.ncols, a.cell_base[l] = L.cell_base;
         a.cand_base[l] = L.cand_base, a.cand_cap[l] = L.cand_cap;
+        a.wc_magic[l] = L.wcell > 0 ? ((1u << 20) + L.wcell - 1) / L.wcell : 0u;
+        a.hc_magic[l] = L.hcell > 0 ? ((1u << 20) + L.hcell - 1) / L.hcell : 0u;
     }
     a.tile_base[g.nlevels] = g.ftiles_per_frame;
     if (part == 0)
