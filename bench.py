@@ -264,12 +264,39 @@ def committed_valu(kernel, workload, launch_frames):
     return None if v is None else v * launch_frames
 
 
+def config4_data(orbx, nq, ndb):
+    """Relocalisation-scale matching data: a random database (splitmix64 seed 1); query i = database row
+    i*(ndb/nq) with 0..80 distinct bits flipped (seed 2); next to every tenth source row sits a
+    near-duplicate (4 further flipped bits), so that best and second best are close and the ratio test fails."""
+    db = orbx.synth_descriptors(1, ndb)
+    rng = np.random.default_rng(2)
+    step = ndb // nq
+    rows = np.arange(nq, dtype=np.int64) * step
+    bits = np.unpackbits(db[rows], axis=1)
+    for i in range(nq):
+        bits[i, rng.choice(256, size=int(rng.integers(0, 81)), replace=False)] ^= 1
+        if i % 10 == 0:
+            b2 = np.unpackbits(db[rows[i]])
+            b2[rng.choice(256, size=4, replace=False)] ^= 1
+            db[rows[i] + 1] = np.packbits(b2)
+    return db, np.packbits(bits, axis=1), rows
+
+
+def numpy_top2(q, db):
+    """Single pass of the reference's bookkeeping over all rows for one query, vectorised."""
+    d = np.bitwise_count(db.view(np.uint64) ^ q.view(np.uint64)).sum(axis=1).astype(np.int64)
+    key = d * (1 << 32) + np.arange(len(db))
+    two = np.partition(key, 1)[:2]
+    two.sort()
+    return int(two[0] & 0xFFFFFFFF), int(two[0] >> 32), int(two[1] >> 32)
+
+
 def bench_hamming(orbx, torch, stream):
     """2000 queries x 1M database rows resident in HBM (one GPU's view of the sharded relocalisation match)."""
     nq, ndb = 2000, 1_000_000
-    db = torch.from_numpy(orbx.synth_descriptors(1, ndb)).cuda()
-    q = db[:: ndb // nq][:nq].clone()
-    q[:, 0] ^= 0x5A
+    hdb, hq, _ = config4_data(orbx, nq, ndb)
+    db = torch.from_numpy(hdb).cuda()
+    q = torch.from_numpy(hq).cuda()
     best = torch.zeros(nq, dtype=torch.int32, device="cuda")
     d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
     d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
@@ -294,9 +321,15 @@ def bench_hamming(orbx, torch, stream):
     pairs = nq * ndb
     rate = pairs / sec
     peak_pairs = VALU_LANE_OPS_PER_S / OPS_PER_PAIR
-    ok = bool((best.cpu().numpy() == np.arange(nq) * (ndb // nq)).all())
+    hb, h1, h2 = best.cpu().numpy(), d1.cpu().numpy().astype(np.int64), d2.cpu().numpy().astype(np.int64)
+    # bit-exact check of a sample of queries against a numpy pass over the whole database
+    ok = True
+    for i in range(0, nq, nq // 40):
+        ok = ok and numpy_top2(hq[i], hdb) == (int(hb[i]), int(h1[i]), int(h2[i]))
+    accepted = int(m.ratio_test(h1.astype(np.uint16), h2.astype(np.uint16))[1])
     return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
-            "self_check": ok,
+            "accepted_matches": accepted, "ratio": 0.75, "th": 50, "self_check": bool(ok),
+            "self_check_what": "40 of the queries against a numpy single pass over all rows (index, d1, d2)",
             "roofline": {"bound": "valu-int32", "achieved": round(rate * OPS_PER_PAIR / 1e12, 3),
                          "peak": round(VALU_LANE_OPS_PER_S / 1e12, 3), "unit": "Tlane-op/s",
                          "frac": round(rate / peak_pairs, 4),
@@ -309,13 +342,9 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
     from orbslam2_amd.sharded import ShardedMatcher, shard_bounds
     nq, ndb = 2000, 1_000_000
     lo, hi = shard_bounds(ndb, rank, world)
-    full = orbx.synth_descriptors(1, ndb)
-    step = ndb // nq
-    q = full[::step][:nq].copy()
-    q[:, 0] ^= 0x5A
+    full, q, _ = config4_data(orbx, nq, ndb)
     db = torch.from_numpy(full[lo:hi].copy()).cuda()
     dq = torch.from_numpy(q).cuda()
-    del full
     best = torch.zeros(nq, dtype=torch.int32, device="cuda")
     d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
     d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
@@ -340,7 +369,11 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     sec = float(dt.item()) / reps
-    ok = bool((res[0] == np.arange(nq) * step).all())
+    ok = True
+    if rank == 0:
+        for i in range(0, nq, nq // 20):
+            ok = ok and numpy_top2(q[i], full) == (int(res[0][i]), int(res[1][i]), int(res[2][i]))
+    del full
     rate = nq * ndb / sec
     return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
             "shards": world, "exchange": "all_gather of 12 B per query and rank, host merge", "self_check": ok,
