@@ -200,6 +200,27 @@ int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoint *k1, con
                                    float min_y, float max_y, float *prev_matched, int window_size, float nnratio,
                                    int check_orientation, int *matches12, int64_t *pair_count);
 
+/* The same search for every consecutive pair (frame t, frame t+1), t = 0 .. nframes-2, of a batch
+ * whose keypoints and descriptors are in device memory in the layout of orbx_batch_device_results
+ * (frame f at +f*max_keypoints entries).  Runs entirely on the GPU, asynchronously on the matcher's
+ * stream: one wave per pair replays the order-dependent pass of src/ORBmatcher.cc:446-516 and the
+ * rotation check (:502-541).  All pointers are device pointers.
+ *   d_prev_matched      (nframes-1) x max_keypoints x 2 floats, the search centres (vbPrevMatched); NULL:
+ *                       the keypoints' own positions, as Tracking::MonocularInitialization sets them
+ *                       (src/Tracking.cc:585-587)
+ *   d_prev_matched_out  same shape or NULL; receives the matched positions (:544-546), other entries untouched
+ *   max_level0          upper bound of level-0 keypoints per frame (sizes the per-pair workspace in LDS;
+ *                       at most 1024).  A pair that exceeds it reports ORBX_E_CAPACITY in d_nmatches.
+ *   d_matches12         (nframes-1) x max_keypoints: index into frame t+1 or -1
+ *   d_nmatches, d_pair_counts  per pair: matches, and candidates whose distance was evaluated */
+int orbx_search_for_initialization_batch_device(orbx_matcher *m, const orbx_keypoint *d_keypoints,
+                                                const uint8_t *d_descriptors, const int32_t *d_counts,
+                                                int max_keypoints, int nframes, int max_level0, float min_x,
+                                                float max_x, float min_y, float max_y, const float *d_prev_matched,
+                                                float *d_prev_matched_out, int window_size, float nnratio,
+                                                int check_orientation, int32_t *d_matches12, int32_t *d_nmatches,
+                                                int32_t *d_pair_counts);
+
 /* ---------------------------------------------------------------- synthetic input */
 
 /* Deterministic test/benchmark image (splitmix64 stream seeded with `seed`): gray 128 canvas,

@@ -1265,6 +1265,28 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
     return nmatches;
 }
 
+extern "C" int orbx_search_for_initialization_batch_device(orbx_matcher *m, const orbx_keypoint *d_keypoints,
+                                                           const uint8_t *d_descriptors, const int32_t *d_counts,
+                                                           int max_keypoints, int nframes, int max_level0, float min_x,
+                                                           float max_x, float min_y, float max_y,
+                                                           const float *d_prev_matched, float *d_prev_matched_out,
+                                                           int window_size, float nnratio, int check_orientation,
+                                                           int32_t *d_matches12, int32_t *d_nmatches,
+                                                           int32_t *d_pair_counts)
+{
+    if (!m || !d_keypoints || !d_descriptors || !d_counts || !d_matches12 || !d_nmatches || !d_pair_counts ||
+        max_keypoints < 1 || max_keypoints > 65535 || nframes < 1 || max_level0 < 1 || max_level0 > 1024 ||
+        !(max_x > min_x) || !(max_y > min_y) || window_size < 0)
+        return ORBX_E_ARG;
+    if (nframes < 2)
+        return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(orbx_launch_search_init(d_keypoints, d_descriptors, d_counts, max_keypoints, nframes - 1, max_level0, min_x,
+                                    max_x, min_y, max_y, d_prev_matched, d_prev_matched_out, window_size, nnratio,
+                                    check_orientation, d_matches12, d_nmatches, d_pair_counts, m->stream));
+    return ORBX_OK;
+}
+
 // ------------------------------------------------------------------ synthetic inputs
 
 static inline uint64_t splitmix64(uint64_t &s)

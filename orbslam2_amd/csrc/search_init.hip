@@ -1,0 +1,309 @@
+// ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:433-549 of the reference) for many frame
+// pairs at once, entirely on the GPU: one wave per pair (frame t, frame t+1) of a batch whose
+// keypoints and descriptors already sit in device memory.
+//
+// The pass over the keypoints of frame 1 is order dependent (a keypoint of frame 2 that is already
+// matched at distance <= d is skipped, :471-472, and matches are stolen, :492-499), so the wave walks
+// them in order; the 64 lanes share the candidates of one keypoint.  Only level-0 keypoints take
+// part (:450-451 and the level arguments of GetFeaturesInArea :455).  A candidate of
+// Frame::GetFeaturesInArea (src/Frame.cc:349-407) is a keypoint whose grid cell (PosInGrid, rounded,
+// src/Frame.cc:409-420) lies in the cell window of the query (floor/ceil) and whose coordinates
+// differ by less than r; the reference visits them cell column by cell column, each cell in
+// keypoint order.  So the wave first sorts the level-0 keypoints of frame 2 that have a cell by
+// (cell column, cell row, keypoint index) into LDS, descriptors included: the candidates of a query
+// then lie in one contiguous range of positions (its cell columns), the visiting order is the
+// position order, and the packed key  distance<<16 | position  orders candidates exactly like the
+// strict '<' updates of that visit.  The two smallest keys of the wave are bestDist / bestDist2 /
+// bestIdx2.
+#include "orbx_internal.h"
+
+extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);  // wave-wide minimum (device library)
+
+#define SFI_COLS 64  // FRAME_GRID_COLS (include/Frame.h:38)
+#define SFI_ROWS 48  // FRAME_GRID_ROWS
+#define SFI_DSTRIDE 9  // dwords per staged descriptor (8 + 1 pad: lanes hit different LDS banks)
+#define SFI_NONE 0xffffu
+
+struct SfiArgs {
+    int max_kp, npairs, cap0, check_ori, th_low, histo;
+    float min_x, min_y, inv_w, inv_h, r, ratio, factor;
+};
+
+// bytes of dynamic LDS for `cap0` level-0 keypoints per frame
+size_t orbx_search_init_lds_bytes(int cap0)
+{
+    return (size_t)cap0 * (SFI_DSTRIDE * 4 + 4 * 7 + 2 * 6 + 4);
+}
+
+__device__ __forceinline__ int lanes_below64(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restrict__ kp,
+                                                    const uint8_t *__restrict__ desc, const int *__restrict__ counts,
+                                                    const float *__restrict__ prev_in, float *__restrict__ prev_out,
+                                                    int *__restrict__ matches12, int *__restrict__ nmatches,
+                                                    int *__restrict__ pair_count, SfiArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int cap = a.cap0;
+    // frame 2, level 0, sorted by (cell, keypoint index)
+    uint32_t *d2 = lds;                                                   // cap * 9 dwords
+    float *x2 = reinterpret_cast<float *>(d2 + (size_t)cap * SFI_DSTRIDE);  // coordinates
+    float *y2 = x2 + cap;
+    float *ang2 = y2 + cap;
+    uint32_t *skey = reinterpret_cast<uint32_t *>(ang2 + cap);  // sort keys in keypoint order: cell << 16 | index
+    // frame 1, level 0, in keypoint order
+    float *x1 = reinterpret_cast<float *>(skey + cap);  // search centre (vbPrevMatched)
+    float *y1 = x1 + cap;
+    float *ang1 = y1 + cap;
+    uint16_t *cell2 = reinterpret_cast<uint16_t *>(ang1 + cap);  // grid column << 8 | grid row
+    uint16_t *idx2 = cell2 + cap;                                // index in frame 2's keypoint array
+    uint16_t *mdist = idx2 + cap;                                // vMatchedDistance
+    uint16_t *m21 = mdist + cap;                                 // vnMatches21 as position in frame 1's list
+    uint16_t *idx1 = m21 + cap;                                  // index in frame 1's keypoint array
+    uint16_t *m12 = idx1 + cap;                                  // vnMatches12 as position in frame 2's list
+    uint8_t *bin1 = reinterpret_cast<uint8_t *>(m12 + cap);      // rotation bin of an accepted match, 0xff: none
+    __shared__ int hist[32];
+    __shared__ int colstart[SFI_COLS + 1];  // first sorted position of each cell column
+
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n1 = min(counts[p], a.max_kp), n2 = min(counts[p + 1], a.max_kp);
+    const orbx_keypoint *k1 = kp + (size_t)p * a.max_kp, *k2 = kp + (size_t)(p + 1) * a.max_kp;
+    const uint32_t *dsc1 = reinterpret_cast<const uint32_t *>(desc) + (size_t)p * a.max_kp * 8;
+    const uint32_t *dsc2 = reinterpret_cast<const uint32_t *>(desc) + (size_t)(p + 1) * a.max_kp * 8;
+    int *out12 = matches12 + (size_t)p * a.max_kp;
+    for (int i = lane; i < a.max_kp; i += 64)
+        out12[i] = -1;
+    if (lane < 32)
+        hist[lane] = 0;
+
+    // ---- level-0 keypoints of frame 2 that lie in a grid cell: sort keys, in keypoint order ----
+    int n20 = 0, n10 = 0;
+    for (int i0 = 0; i0 < n2; i0 += 64) {
+        const int i = i0 + lane;
+        int cell = SFI_NONE;
+        if (i < n2 && k2[i].octave == 0) {
+            // Frame::PosInGrid: rounded cell; keypoints outside the grid are in no cell
+            const int px = (int)roundf((k2[i].x - a.min_x) * a.inv_w), py = (int)roundf((k2[i].y - a.min_y) * a.inv_h);
+            if (px >= 0 && px < SFI_COLS && py >= 0 && py < SFI_ROWS)
+                cell = (px << 8) | py;
+        }
+        const unsigned long long bm = __ballot(cell != (int)SFI_NONE);
+        const int pos = n20 + lanes_below64(bm);
+        if (cell != (int)SFI_NONE && pos < cap)
+            skey[pos] = ((uint32_t)cell << 16) | (uint32_t)i;
+        n20 += __popcll(bm);
+    }
+    for (int i0 = 0; i0 < n1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool lvl0 = i < n1 && k1[i].octave <= 0;  // the reference skips octave > 0
+        const unsigned long long bm = __ballot(lvl0);
+        const int pos = n10 + lanes_below64(bm);
+        if (lvl0 && pos < cap) {
+            const size_t pi = ((size_t)p * a.max_kp + i) * 2;
+            x1[pos] = prev_in ? prev_in[pi] : k1[i].x;
+            y1[pos] = prev_in ? prev_in[pi + 1] : k1[i].y;
+            ang1[pos] = k1[i].angle;
+            idx1[pos] = (uint16_t)i;
+            m12[pos] = (uint16_t)SFI_NONE;
+            bin1[pos] = 0xff;
+        }
+        n10 += __popcll(bm);
+    }
+    if (n10 > cap || n20 > cap) {  // more level-0 keypoints than the caller allowed for
+        if (lane == 0)
+            nmatches[p] = ORBX_E_CAPACITY, pair_count[p] = 0;
+        return;
+    }
+    __syncthreads();
+    // ---- rank sort (keys are distinct), then everything of frame 2 goes to its sorted position ----
+    for (int e0 = 0; e0 < n20; e0 += 64) {
+        const int e = e0 + lane;
+        const uint32_t mine = e < n20 ? skey[e] : 0xffffffffu;
+        int rank = 0;
+        for (int q = 0; q < n20; q++)
+            rank += skey[q] < mine;  // the same address in every lane
+        if (e < n20) {
+            const int i = mine & 0xffffu;
+            x2[rank] = k2[i].x, y2[rank] = k2[i].y, ang2[rank] = k2[i].angle;
+            cell2[rank] = (uint16_t)(mine >> 16);
+            idx2[rank] = (uint16_t)i;
+            mdist[rank] = (uint16_t)SFI_NONE;
+            m21[rank] = (uint16_t)SFI_NONE;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                d2[rank * SFI_DSTRIDE + k] = dsc2[(size_t)i * 8 + k];
+        }
+    }
+    __syncthreads();
+    // colstart[c] = number of sorted entries in cell columns below c
+    for (int c = lane; c <= SFI_COLS; c += 64) {
+        int lo = 0, hi = n20;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((cell2[mid] >> 8) < c)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        colstart[c] = lo;
+    }
+    __syncthreads();
+
+    // ---- the order-dependent pass (:446-516) ----
+    int npairs = 0;
+    // the query of step j+1 (search centre, descriptor) is fetched while step j runs
+    float nqx = 0.f, nqy = 0.f;
+    uint32_t nq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto fetch_query = [&](int j) {
+        if (j < n10) {
+            nqx = x1[j], nqy = y1[j];
+            const int i1 = __builtin_amdgcn_readfirstlane((int)idx1[j]);
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                nq[k] = dsc1[(size_t)i1 * 8 + k];  // the same address in every lane: scalar loads
+        }
+    };
+    fetch_query(0);
+    for (int j = 0; j < n10; j++) {
+        const float qx = nqx, qy = nqy;
+        uint32_t q[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            q[k] = nq[k];
+        fetch_query(j + 1);
+        // cell window of GetFeaturesInArea; an empty window leaves the keypoint unmatched
+        const int cx0 = max(0, (int)floorf((qx - a.min_x - a.r) * a.inv_w));
+        const int cx1 = min(SFI_COLS - 1, (int)ceilf((qx - a.min_x + a.r) * a.inv_w));
+        const int cy0 = max(0, (int)floorf((qy - a.min_y - a.r) * a.inv_h));
+        const int cy1 = min(SFI_ROWS - 1, (int)ceilf((qy - a.min_y + a.r) * a.inv_h));
+        if (cx0 >= SFI_COLS || cx1 < 0 || cy0 >= SFI_ROWS || cy1 < 0)
+            continue;
+        const int c_lo = __builtin_amdgcn_readfirstlane(colstart[cx0]);
+        const int c_hi = cx1 >= cx0 ? __builtin_amdgcn_readfirstlane(colstart[cx1 + 1]) : c_lo;
+        uint32_t b1 = 0xffffffffu, b2 = 0xffffffffu;
+        for (int c = c_lo + lane; c < c_hi; c += 64) {
+            const int py = cell2[c] & 0xff;
+            const bool in = py >= cy0 && py <= cy1 && fabsf(x2[c] - qx) < a.r && fabsf(y2[c] - qy) < a.r;
+            if (in) {
+                npairs++;
+                const uint32_t *r = d2 + c * SFI_DSTRIDE;
+                uint32_t d = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    d += __popc(q[k] ^ r[k]);
+                if (!((uint32_t)mdist[c] <= d)) {  // vMatchedDistance starts at INT_MAX
+                    const uint32_t key = (d << 16) | (uint32_t)c;
+                    const uint32_t hi = max(b1, key);
+                    b1 = min(b1, key);
+                    b2 = min(b2, hi);
+                }
+            }
+        }
+        const uint32_t w1 = __ockl_wfred_min_u32(b1);
+        if (w1 == 0xffffffffu)
+            continue;
+        // the runner-up is the winner lane's second key or another lane's first (keys are distinct)
+        const uint32_t w2 = __ockl_wfred_min_u32(b1 == w1 ? b2 : b1);
+        const int best = (int)(w1 >> 16);
+        const float best2 = w2 == 0xffffffffu ? 2147483648.0f : (float)(int)(w2 >> 16);  // INT_MAX as float
+        if (best <= a.th_low && (float)best < best2 * a.ratio) {
+            const int c = (int)(w1 & 0xffffu);
+            if (lane == 0) {
+                const int old = m21[c];
+                if (old != (int)SFI_NONE)
+                    m12[old] = (uint16_t)SFI_NONE;
+                m12[j] = (uint16_t)c;
+                m21[c] = (uint16_t)j;
+                mdist[c] = (uint16_t)best;
+                if (a.check_ori) {
+                    float rot = ang1[j] - ang2[c];
+                    if (rot < 0.0f)
+                        rot += 360.0f;
+                    int bin = (int)roundf(rot * a.factor);
+                    if (bin == a.histo)
+                        bin = 0;
+                    bin1[j] = (uint8_t)bin;
+                    hist[bin & 31]++;
+                }
+            }
+            __syncthreads();  // lane 0's updates are read by every lane from here on
+        }
+    }
+    __syncthreads();
+
+    // ---- rotation consistency (:502-541, ComputeThreeMaxima :1698-1739) ----
+    int i1m = -1, i2m = -1, i3m = -1;
+    if (a.check_ori) {
+        int max1 = 0, max2 = 0, max3 = 0;
+        for (int i = 0; i < a.histo; i++) {
+            const int s = hist[i];
+            if (s > max1) {
+                max3 = max2, max2 = max1, max1 = s;
+                i3m = i2m, i2m = i1m, i1m = i;
+            } else if (s > max2) {
+                max3 = max2, max2 = s;
+                i3m = i2m, i2m = i;
+            } else if (s > max3) {
+                max3 = s;
+                i3m = i;
+            }
+        }
+        if ((float)max2 < 0.1f * (float)max1)
+            i2m = -1, i3m = -1;
+        else if ((float)max3 < 0.1f * (float)max1)
+            i3m = -1;
+    }
+    int nm = 0;
+    for (int j = lane; j < n10; j += 64) {
+        int c = m12[j];
+        if (c != (int)SFI_NONE && a.check_ori) {
+            const int b = bin1[j];
+            if (!(b == i1m || b == i2m || b == i3m))
+                c = SFI_NONE;
+        }
+        if (c != (int)SFI_NONE) {
+            nm++;
+            const int i1 = idx1[j];
+            out12[i1] = idx2[c];
+            if (prev_out) {  // :544-546
+                const size_t pi = ((size_t)p * a.max_kp + i1) * 2;
+                prev_out[pi] = x2[c], prev_out[pi + 1] = y2[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        nm += __shfl_xor(nm, s, 64);
+        npairs += __shfl_xor(npairs, s, 64);
+    }
+    if (lane == 0)
+        nmatches[p] = nm, pair_count[p] = npairs;
+}
+
+hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_desc, const int *d_counts, int max_kp,
+                                   int npairs, int cap0, float min_x, float max_x, float min_y, float max_y,
+                                   const float *d_prev_in, float *d_prev_out, int window, float ratio, int check_ori,
+                                   int *d_matches12, int *d_nmatches, int *d_pair_count, hipStream_t s)
+{
+    if (npairs <= 0)
+        return hipSuccess;
+    SfiArgs a;
+    a.max_kp = max_kp, a.npairs = npairs, a.cap0 = cap0, a.check_ori = check_ori;
+    a.th_low = ORBX_TH_LOW, a.histo = ORBX_HISTO_LENGTH;
+    a.min_x = min_x, a.min_y = min_y;
+    a.inv_w = (float)SFI_COLS / (max_x - min_x), a.inv_h = (float)SFI_ROWS / (max_y - min_y);
+    a.r = (float)window, a.ratio = ratio, a.factor = ORBX_HISTO_LENGTH / 360.0f;
+    const size_t lds = orbx_search_init_lds_bytes(cap0);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_init),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+    }
+    k_search_init<<<npairs, 64, lds, s>>>(d_kp, d_desc, d_counts, d_prev_in, d_prev_out, d_matches12, d_nmatches,
+                                          d_pair_count, a);
+    return hipGetLastError();
+}

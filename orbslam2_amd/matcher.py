@@ -114,3 +114,15 @@ class ORBmatcher:
             bounds[2], bounds[3], L.ptr(vbPrevMatched), windowSize, self.mfNNratio, int(self.mbCheckOrientation),
             L.ptr(m12), C.byref(pairs)), "orbx_search_for_initialization")
         return n, m12, pairs.value
+
+    def search_for_initialization_batch_device(self, d_keypoints, d_descriptors, d_counts, max_keypoints, nframes,
+                                               max_level0, bounds, d_matches12, d_nmatches, d_pair_counts,
+                                               windowSize=100, d_prev_matched=None, d_prev_matched_out=None):
+        """SearchForInitialization of every consecutive frame pair of a device-resident batch (the arrays
+        of ORBextractor.device_results()); all arguments are device addresses (ints).  Asynchronous on
+        the matcher's stream."""
+        L.check(self._lib.orbx_search_for_initialization_batch_device(
+            self._handle(), d_keypoints, d_descriptors, d_counts, max_keypoints, nframes, max_level0, bounds[0],
+            bounds[1], bounds[2], bounds[3], d_prev_matched, d_prev_matched_out, windowSize, self.mfNNratio,
+            int(self.mbCheckOrientation), d_matches12, d_nmatches, d_pair_counts),
+            "orbx_search_for_initialization_batch_device")

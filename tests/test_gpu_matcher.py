@@ -150,3 +150,54 @@ def test_golden_top2_and_device_sharded_path():
 
     sb, s1, s2 = ShardedMatcher(local, 0, 1, device="cuda").match(dq, 0)
     assert np.array_equal(sb, g["best"]) and np.array_equal(s1, g["d1"]) and np.array_equal(s2, g["d2"])
+
+
+@pytest.mark.parametrize("ratio,ori,win", [(0.9, True, 100), (0.9, False, 100), (0.6, True, 30), (0.9, True, 400)])
+def test_search_for_initialization_batch_device_vs_oracle(oracle, ratio, ori, win):
+    """Consecutive pairs of a device-resident batch, matched on the GPU, against the oracle pair by pair."""
+    import torch
+    w, h, nf = 1241, 376, 5
+    base = orbx.synth_image(0x0B5EED00, w, h, 0)
+    rng = np.random.default_rng(7)
+    frames = []
+    for t in range(nf):
+        img = np.roll(base, (2 * t, 3 * t), axis=(0, 1)).astype(np.int16) + rng.integers(-2, 3, size=base.shape)
+        frames.append(np.clip(img, 0, 255).astype(np.uint8))
+    frames[3] = orbx.synth_image(99, w, h, 1)  # a flat frame: few or no keypoints on one side of two pairs
+    ex = orbx.ORBextractor(2000, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=nf)
+    ex.extract_batch_host(frames)
+    host = [ex.batch_download(f) for f in range(nf)]
+    d_kp, d_desc, d_cnt, cap = ex.device_results()
+    m12 = torch.full((nf - 1, cap), -7, dtype=torch.int32, device="cuda")
+    nm = torch.zeros(nf - 1, dtype=torch.int32, device="cuda")
+    npairs = torch.zeros(nf - 1, dtype=torch.int32, device="cuda")
+    prev_out = torch.full((nf - 1, cap, 2), -1.0, dtype=torch.float32, device="cuda")
+    m = orbx.ORBmatcher(ratio, ori)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    bounds = (0.0, float(w), 0.0, float(h))
+    m.search_for_initialization_batch_device(d_kp, d_desc, d_cnt, cap, nf, 600, bounds, m12.data_ptr(),
+                                             nm.data_ptr(), npairs.data_ptr(), windowSize=win,
+                                             d_prev_matched_out=prev_out.data_ptr())
+    torch.cuda.synchronize()
+    m12, nm, npairs, prev_out = m12.cpu().numpy(), nm.cpu().numpy(), npairs.cpu().numpy(), prev_out.cpu().numpy()
+    total = 0
+    for t in range(nf - 1):
+        (k1, d1), (k2, d2) = host[t], host[t + 1]
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32).copy()
+        on, om12, opairs = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev, win, ratio, ori)
+        assert nm[t] == on and npairs[t] == opairs
+        assert np.array_equal(m12[t, :len(k1)], om12)
+        assert (m12[t, len(k1):] == -1).all()
+        hit = om12 >= 0
+        assert np.array_equal(prev_out[t, :len(k1)][hit], prev[hit])
+        assert (prev_out[t, :len(k1)][~hit] == -1.0).all()
+        total += on
+    assert total > 100
+    # a workspace smaller than the level-0 keypoints is reported per pair
+    m12b = torch.zeros((nf - 1, cap), dtype=torch.int32, device="cuda")
+    nmb = torch.zeros(nf - 1, dtype=torch.int32, device="cuda")
+    npb = torch.zeros(nf - 1, dtype=torch.int32, device="cuda")
+    m.search_for_initialization_batch_device(d_kp, d_desc, d_cnt, cap, nf, 8, bounds, m12b.data_ptr(),
+                                             nmb.data_ptr(), npb.data_ptr(), windowSize=win)
+    torch.cuda.synchronize()
+    assert nmb.cpu().numpy()[0] == -3  # ORBX_E_CAPACITY
