@@ -5,6 +5,7 @@
 # Usage (on the GPU box, from the repository root): bash tools/collect_profiles.sh <out-dir-under-gpurun_out>
 set -o pipefail
 OUT=$PWD/gpurun_out/${1:-r01}
+rm -rf "$OUT"
 mkdir -p "$OUT"
 REPO=$PWD
 export TMPDIR=/tmp
@@ -19,4 +20,8 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python3 $EXCL > "$OUT/pmc_sq.log" 2>&1 || exit 1
 timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal_fetch" -- $REPO/tools/ubench_fetch > "$OUT/cal_fetch.log" 2>&1 || exit 1
 timeout -s KILL 60 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cal_write" -- $REPO/tools/ubench_fetch > "$OUT/cal_write.log" 2>&1 || exit 1
+cd $REPO
+timeout -k 10 200 python3 tools/pcie_rate.py > "$OUT/pcie_rate.log" 2>/dev/null || exit 1
+timeout -k 10 200 python3 tools/latency_breakdown.py > "$OUT/latency_breakdown.log" 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/config5_pairs.py > "$OUT/config5_pairs.json" 2>/dev/null || exit 1
 echo collected

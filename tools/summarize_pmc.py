@@ -18,7 +18,8 @@ def load(d):
     files = glob.glob(os.path.join(d, "vm", "*counter_collection.csv")) + glob.glob(
         os.path.join(d, "*", "*counter_collection.csv"))
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(files[0])):
+    files.sort(key=os.path.getmtime)  # a directory merged from several runs: the newest pass counts
+    for r in csv.DictReader(open(files[-1])):
         agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
