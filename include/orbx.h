@@ -153,6 +153,29 @@ int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, int *xs, int
 int orbx_debug_octree(int device, const int *xs, const int *ys, const int *resp, int n, int region_w, int region_h,
                       int quota, int *out_idx, int cap, int *n_out);
 
+/* ---------------------------------------------------------------- stereo matching */
+
+/* Frame::ComputeStereoMatches (src/Frame.cc:534-708) for every frame of the batches that a left and
+ * a right extractor handle processed last (same image size, settings, batch size and device; frame f
+ * of the left batch pairs with frame f of the right batch).  For each left keypoint: the right
+ * keypoints listed in its image row (the reference's vRowIndices), octave within +-1, u in
+ * [uL - mbf/mb, uL]; best descriptor distance (first index wins ties) below (TH_HIGH+TH_LOW)/2;
+ * 11x11 window slid over 11 positions at the keypoint's pyramid level; parabola fit; finally the
+ * matches whose window distance reaches 1.5*1.4*median are dropped.  mb = stereo baseline (mb of the
+ * Frame), mbf = baseline * fx.  d_uright / d_depth: device arrays of batch x max_keypoints floats
+ * (frame f at +f*max_keypoints; mvuRight / mvDepth, -1 where unmatched; entries past a frame's
+ * keypoint count are -1); d_nmatches: matches per frame.  Asynchronous on the left handle's stream;
+ * the right handle's stream is ordered before and after it.  Keypoints whose row lies outside the
+ * image (the reference would index out of range) stay unmatched; a frame without any match is left
+ * as it is (the reference reads the median of an empty list). */
+int orbx_compute_stereo_matches_device(orbx_extractor *left, orbx_extractor *right, float mb, float mbf,
+                                       float *d_uright, float *d_depth, int32_t *d_nmatches);
+/* Host form for one frame of the batch: fills uright / depth (cap entries available) for the
+ * *n_keypoints left keypoints of `frame`; returns the number of matches or a negative error.  The
+ * batch is matched once and kept until either handle processes a new batch. */
+int orbx_compute_stereo_matches(orbx_extractor *left, orbx_extractor *right, int frame, float mb, float mbf,
+                                float *uright, float *depth, int cap, int *n_keypoints);
+
 /* ---------------------------------------------------------------- matcher */
 
 /* replaces ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1744-1760): Hamming distance of two

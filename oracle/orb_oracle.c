@@ -1123,4 +1123,170 @@ int orc_search_for_initialization(const orc_keypoint *k1, const uint8_t *d1, int
 }
 
 /* trace accessors for the Python binding */
+/* ------------------------------------------------------------------ stereo matching */
+
+typedef struct {
+    int dist, idx;
+} orc_dist_idx;
+
+static int orc_cmp_dist_idx(const void *a, const void *b)
+{
+    const orc_dist_idx *A = (const orc_dist_idx *)a, *B = (const orc_dist_idx *)b;
+    if (A->dist != B->dist)
+        return A->dist < B->dist ? -1 : 1;
+    return A->idx < B->idx ? -1 : (A->idx > B->idx ? 1 : 0);
+}
+
+/* Frame::ComputeStereoMatches, src/Frame.cc:534-708.  TH_HIGH = 100, TH_LOW = 50 (src/ORBmatcher.cc:37-38).
+ * kL/dL, kR/dR: keypoints (level-0 coordinates, octave) and descriptors of the left and right image;
+ * pyrL/pyrR: the nlevels pyramid images of both (mvImagePyramid), widths lw, heights lh, row strides
+ * lsL/lsR; sf/inv: scale and inverse scale factors; mb, mbf: baseline and baseline * fx.
+ * uright/depth receive nL entries (-1 where unmatched); sad (may be NULL) the best window distance
+ * of the accepted matches before the median filter, -1 elsewhere.  Returns the number of matches left.
+ * Rows outside the image (the reference would index out of range) are skipped. */
+int orc_compute_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL, const orc_keypoint *kR,
+                               const uint8_t *dR, int nR, const uint8_t *const *pyrL, const uint8_t *const *pyrR,
+                               const int *lw, const int *lh, const int *lsL, const int *lsR, int nlevels,
+                               const float *sf, const float *inv, float mb, float mbf, float *uright, float *depth,
+                               int *sad)
+{
+    enum { TH_HIGH = 100, TH_LOW = 50 };
+    (void)nlevels;
+    for (int i = 0; i < nL; i++) {
+        uright[i] = -1.0f;
+        depth[i] = -1.0f;
+        if (sad)
+            sad[i] = -1;
+    }
+    const int thOrbDist = (TH_HIGH + TH_LOW) / 2;
+    const int nRows = lh[0];
+    /* :543-561 row table: right keypoint iR is listed in every row of [floor(y-r), ceil(y+r)] */
+    int *cnt = (int *)calloc((size_t)nRows + 1, sizeof(int));
+    for (int iR = 0; iR < nR; iR++) {
+        const float kpY = kR[iR].y;
+        const float r = 2.0f * sf[kR[iR].octave];
+        const int maxr = (int)ceil(kpY + r), minr = (int)floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows)
+                cnt[yi + 1]++;
+    }
+    for (int y = 0; y < nRows; y++)
+        cnt[y + 1] += cnt[y];
+    int *rows = (int *)malloc(sizeof(int) * (size_t)(cnt[nRows] > 0 ? cnt[nRows] : 1));
+    int *fill = (int *)malloc(sizeof(int) * (size_t)(nRows + 1));
+    memcpy(fill, cnt, sizeof(int) * (size_t)(nRows + 1));
+    for (int iR = 0; iR < nR; iR++) {
+        const float kpY = kR[iR].y;
+        const float r = 2.0f * sf[kR[iR].octave];
+        const int maxr = (int)ceil(kpY + r), minr = (int)floor(kpY - r);
+        for (int yi = minr; yi <= maxr; yi++)
+            if (yi >= 0 && yi < nRows)
+                rows[fill[yi]++] = iR;
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    orc_dist_idx *vd = (orc_dist_idx *)malloc(sizeof(orc_dist_idx) * (size_t)(nL > 0 ? nL : 1));
+    int nvd = 0;
+    for (int iL = 0; iL < nL; iL++) {
+        const orc_keypoint *kpL = &kL[iL];
+        const int levelL = kpL->octave;
+        const float vL = kpL->y, uL = kpL->x;
+        const int row = (int)vL; /* vRowIndices[vL]: float index, truncated */
+        if (row < 0 || row >= nRows || cnt[row] == cnt[row + 1])
+            continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0)
+            continue;
+        int bestDist = TH_HIGH;
+        int bestIdxR = 0;
+        for (int c = cnt[row]; c < cnt[row + 1]; c++) {
+            const int iR = rows[c];
+            const orc_keypoint *kpR = &kR[iR];
+            if (kpR->octave < levelL - 1 || kpR->octave > levelL + 1)
+                continue;
+            const float uR = kpR->x;
+            if (uR >= minU && uR <= maxU) {
+                const int dist = orc_popcnt256(dL + (size_t)iL * 32, dR + (size_t)iR * 32);
+                if (dist < bestDist) {
+                    bestDist = dist;
+                    bestIdxR = iR;
+                }
+            }
+        }
+        if (!(bestDist < thOrbDist))
+            continue;
+        /* :619-691 sub-pixel refinement by an 11x11 window slid over 11 positions at the keypoint's level */
+        const float uR0 = kR[bestIdxR].x;
+        const float scaleFactor = inv[levelL];
+        const float scaleduL = roundf(kpL->x * scaleFactor);
+        const float scaledvL = roundf(kpL->y * scaleFactor);
+        const float scaleduR0 = roundf(uR0 * scaleFactor);
+        const int w = 5, L = 5;
+        const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+        if (iniu < 0 || endu >= (float)lw[levelL])
+            continue;
+        const int su = (int)scaleduL, sv = (int)scaledvL, sr = (int)scaleduR0;
+        const uint8_t *IL = pyrL[levelL], *IR = pyrR[levelL];
+        const int pL = lsL[levelL], pR = lsR[levelL];
+        const int cL = IL[(size_t)sv * pL + su];
+        int best = INT_MAX, bestinc = 0;
+        float vDists[11];
+        for (int incR = -L; incR <= L; incR++) {
+            const int cR = IR[(size_t)sv * pR + sr + incR];
+            /* cv::norm(IL, IR, NORM_L1) on the centre-subtracted float windows: integer valued, exact */
+            int acc = 0;
+            for (int y = -w; y <= w; y++)
+                for (int x = -w; x <= w; x++) {
+                    const int a = IL[(size_t)(sv + y) * pL + su + x] - cL;
+                    const int b = IR[(size_t)(sv + y) * pR + sr + incR + x] - cR;
+                    acc += abs(a - b);
+                }
+            const float dist = (float)acc;
+            if (dist < (float)best) {
+                best = (int)dist;
+                bestinc = incR;
+            }
+            vDists[L + incR] = dist;
+        }
+        if (bestinc == -L || bestinc == L)
+            continue;
+        const float dist1 = vDists[L + bestinc - 1], dist2 = vDists[L + bestinc], dist3 = vDists[L + bestinc + 1];
+        const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+        if (deltaR < -1 || deltaR > 1)
+            continue;
+        float bestuR = sf[levelL] * ((float)scaleduR0 + (float)bestinc + deltaR);
+        float disparity = uL - bestuR;
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+                disparity = 0.01;
+                bestuR = uL - 0.01;
+            }
+            depth[iL] = mbf / disparity;
+            uright[iL] = bestuR;
+            if (sad)
+                sad[iL] = best;
+            vd[nvd].dist = best;
+            vd[nvd].idx = iL;
+            nvd++;
+        }
+    }
+    int left = nvd;
+    if (nvd > 0) { /* :694-707 (the reference reads vDistIdx[0] of an empty vector otherwise) */
+        qsort(vd, (size_t)nvd, sizeof(orc_dist_idx), orc_cmp_dist_idx);
+        const float median = (float)vd[nvd / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nvd - 1; i >= 0; i--) {
+            if ((float)vd[i].dist < thDist)
+                break;
+            uright[vd[i].idx] = -1;
+            depth[vd[i].idx] = -1;
+            left--;
+        }
+    }
+    free(vd);
+    free(fill);
+    free(rows);
+    free(cnt);
+    return left;
+}
+
 int orc_trace_sizeof(void) { return (int)sizeof(orc_trace); }

@@ -241,3 +241,34 @@ def search_for_initialization(k1, d1, k2, d2, bounds, prev_matched, window, nnra
                                             bounds[2], bounds[3], _p(prev_matched), window, nnratio, int(check_ori),
                                             _p(m12), C.byref(pairs))
     return n, m12, pairs.value
+
+
+def compute_stereo_matches(kL, dL, kR, dR, pyrL, pyrR, sf, inv, mb, mbf):
+    """Frame::ComputeStereoMatches on the oracle's data: pyrL/pyrR are lists of level images.
+    Returns (n, uright, depth, sad)."""
+    kL = np.ascontiguousarray(kL, KEYPOINT_DTYPE)
+    kR = np.ascontiguousarray(kR, KEYPOINT_DTYPE)
+    dL = np.ascontiguousarray(dL, np.uint8)
+    dR = np.ascontiguousarray(dR, np.uint8)
+    nl = len(pyrL)
+    pl = [np.ascontiguousarray(a, np.uint8) for a in pyrL]
+    pr = [np.ascontiguousarray(a, np.uint8) for a in pyrR]
+    PT = C.c_void_p * nl
+    IT = C.c_int * nl
+    lw = IT(*[a.shape[1] for a in pl])
+    lh = IT(*[a.shape[0] for a in pl])
+    ls_l = IT(*[a.strides[0] for a in pl])
+    ls_r = IT(*[a.strides[0] for a in pr])
+    sf = np.ascontiguousarray(sf, np.float32)
+    inv = np.ascontiguousarray(inv, np.float32)
+    ur = np.zeros(len(kL), np.float32)
+    dp = np.zeros(len(kL), np.float32)
+    sad = np.zeros(len(kL), np.int32)
+    fn = lib().orc_compute_stereo_matches
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = fn(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), PT(*[a.ctypes.data for a in pl]),
+           PT(*[a.ctypes.data for a in pr]), lw, lh, ls_l, ls_r, nl, _p(sf), _p(inv), mb, mbf, _p(ur), _p(dp), _p(sad))
+    return n, ur, dp, sad

@@ -55,7 +55,17 @@ struct orbx_extractor {
     OrbxGeom geom;      // geometry of the last batch
     int geom_w, geom_h; // image size geom was built for (0 = none)
     bool have_batch;
+    unsigned long long batch_serial;  // counts the batches this handle has processed
     OrbxBuffers buf;
+    // stereo matching workspace (allocated on first use) and the batch pair it holds results for
+    int *st_rowstart;
+    uint16_t *st_sorted;
+    int *st_sad, *st_nmatch;
+    float *st_uright, *st_depth;
+    hipEvent_t ev_stereo;
+    const orbx_extractor *st_right;
+    unsigned long long st_left_serial, st_right_serial;
+    float st_mb, st_mbf;
     OrbxXCoef *d_xtab;
     OrbxYCoef *d_ytab;
     int xtab_cap, ytab_cap;
@@ -271,6 +281,16 @@ static void free_buffers(orbx_extractor *ex)
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
+    void *st[] = {ex->st_rowstart, ex->st_sorted, ex->st_sad, ex->st_nmatch, ex->st_uright, ex->st_depth};
+    for (void *p : st)
+        if (p)
+            (void)hipFree(p);
+    ex->st_rowstart = ex->st_sad = ex->st_nmatch = nullptr;
+    ex->st_sorted = nullptr;
+    ex->st_uright = ex->st_depth = nullptr;
+    if (ex->ev_stereo)
+        (void)hipEventDestroy(ex->ev_stereo);
+    ex->ev_stereo = nullptr;
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
@@ -296,6 +316,14 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->device = p.device;
     ex->geom_w = ex->geom_h = 0;
     ex->have_batch = false;
+    ex->batch_serial = 0;
+    ex->st_rowstart = ex->st_sad = ex->st_nmatch = nullptr;
+    ex->st_sorted = nullptr;
+    ex->st_uright = ex->st_depth = nullptr;
+    ex->ev_stereo = nullptr;
+    ex->st_right = nullptr;
+    ex->st_left_serial = ex->st_right_serial = 0;
+    ex->st_mb = ex->st_mbf = 0.f;
     ex->profiling = false;
     ex->prof_used = 0;
     ex->own_stream = ex->stream = ex->aux_stream = nullptr;
@@ -504,6 +532,7 @@ static int run_pipeline(orbx_extractor *ex)
     if (ex->profiling)
         ex->prof_used++;
     ex->have_batch = true;
+    ex->batch_serial++;
     return ORBX_OK;
 }
 
@@ -1061,6 +1090,90 @@ extern "C" int orbx_ratio_test(int nq, const uint16_t *d1, const uint16_t *d2, i
         n += ok;
     }
     return n;
+}
+
+// ---- Frame::ComputeStereoMatches on the last batches of a left and a right extractor ----
+
+static int stereo_check(const orbx_extractor *left, const orbx_extractor *right)
+{
+    if (!left || !right || left == right)
+        return ORBX_E_ARG;
+    if (!left->have_batch || !right->have_batch)
+        return ORBX_E_STATE;
+    const OrbxGeom &a = left->geom, &b = right->geom;
+    if (left->device != right->device || a.batch != b.batch || a.nlevels != b.nlevels || a.out_cap != b.out_cap ||
+        a.slab != b.slab || left->geom_w != right->geom_w || left->geom_h != right->geom_h ||
+        left->p.scale_factor != right->p.scale_factor)
+        return ORBX_E_ARG;  // the two images of a stereo frame share size and extractor settings
+    return ORBX_OK;
+}
+
+extern "C" int orbx_compute_stereo_matches_device(orbx_extractor *left, orbx_extractor *right, float mb, float mbf,
+                                                  float *d_uright, float *d_depth, int32_t *d_nmatches)
+{
+    int rc = stereo_check(left, right);
+    if (rc != ORBX_OK)
+        return rc;
+    if (!d_uright || !d_depth || !d_nmatches || !(mb > 0.f) || !(mbf > 0.f))
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(left->device));
+    if (!left->st_rowstart) {
+        const OrbxGeom &c = left->cap_geom;
+        const size_t B = (size_t)left->p.max_batch;
+        HIP_TRY(hipMalloc((void **)&left->st_rowstart, B * (size_t)(left->p.max_height + 1) * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&left->st_sorted, B * (size_t)c.out_cap * sizeof(uint16_t)));
+        HIP_TRY(hipMalloc((void **)&left->st_sad, B * (size_t)c.out_cap * sizeof(int)));
+        HIP_TRY(hipEventCreateWithFlags(&left->ev_stereo, hipEventDisableTiming));
+    }
+    // the right image's batch runs on the right handle's stream
+    HIP_TRY(hipEventRecord(left->ev_stereo, right->stream));
+    HIP_TRY(hipStreamWaitEvent(left->stream, left->ev_stereo, 0));
+    HIP_TRY(orbx_launch_stereo(left->geom, left->buf, right->buf, left->sf, left->inv, mb, mbf, left->st_rowstart,
+                               left->st_sorted, left->st_sad, d_uright, d_depth, d_nmatches, left->stream));
+    // the right handle must not start its next batch before these kernels have read its results
+    HIP_TRY(hipEventRecord(left->ev_stereo, left->stream));
+    HIP_TRY(hipStreamWaitEvent(right->stream, left->ev_stereo, 0));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_compute_stereo_matches(orbx_extractor *left, orbx_extractor *right, int frame, float mb, float mbf,
+                                           float *uright, float *depth, int cap, int *n_keypoints)
+{
+    int rc = stereo_check(left, right);
+    if (rc != ORBX_OK)
+        return rc;
+    if (frame < 0 || frame >= left->geom.batch || !uright || !depth || !n_keypoints)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(left->device));
+    if (!left->st_uright) {
+        const size_t n = (size_t)left->p.max_batch * left->cap_geom.out_cap;
+        HIP_TRY(hipMalloc((void **)&left->st_uright, n * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&left->st_depth, n * sizeof(float)));
+        HIP_TRY(hipMalloc((void **)&left->st_nmatch, (size_t)left->p.max_batch * sizeof(int)));
+    }
+    if (left->st_right != right || left->st_left_serial != left->batch_serial ||
+        left->st_right_serial != right->batch_serial || left->st_mb != mb || left->st_mbf != mbf) {
+        rc = orbx_compute_stereo_matches_device(left, right, mb, mbf, left->st_uright, left->st_depth, left->st_nmatch);
+        if (rc != ORBX_OK)
+            return rc;
+        left->st_right = right;
+        left->st_left_serial = left->batch_serial, left->st_right_serial = right->batch_serial;
+        left->st_mb = mb, left->st_mbf = mbf;
+    }
+    int head[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(&head[0], left->buf.out_n + frame, sizeof(int), hipMemcpyDeviceToHost, left->stream));
+    HIP_TRY(hipMemcpyAsync(&head[1], left->st_nmatch + frame, sizeof(int), hipMemcpyDeviceToHost, left->stream));
+    HIP_TRY(hipStreamSynchronize(left->stream));
+    *n_keypoints = head[0];
+    if (head[0] > cap)
+        return ORBX_E_CAPACITY;
+    if (head[0] > 0) {
+        const size_t o = (size_t)frame * left->geom.out_cap;
+        HIP_TRY(hipMemcpyAsync(uright, left->st_uright + o, sizeof(float) * head[0], hipMemcpyDeviceToHost, left->stream));
+        HIP_TRY(hipMemcpyAsync(depth, left->st_depth + o, sizeof(float) * head[0], hipMemcpyDeviceToHost, left->stream));
+        HIP_TRY(hipStreamSynchronize(left->stream));
+    }
+    return head[1];
 }
 
 // ---- SearchForInitialization: candidate windows on the host, distances on the GPU, greedy replay ----

@@ -130,6 +130,9 @@ hipError_t orbx_launch_octree_single(const uint32_t *d_xy, const uint8_t *d_resp
 hipError_t orbx_launch_top2(const uint8_t *d_q, int nq, const uint8_t *d_db, int64_t ndb, int64_t idx_base,
                             uint32_t *d_partial, int chunk_rows, int nchunks, int32_t *d_best, uint16_t *d_d1,
                             uint16_t *d_d2, hipStream_t s);
+hipError_t orbx_launch_stereo(const OrbxGeom &g, const OrbxBuffers &bl, const OrbxBuffers &br, const float *sf,
+                              const float *inv, float mb, float mbf, int *d_rowstart, uint16_t *d_sorted, int *d_sad,
+                              float *d_uright, float *d_depth, int *d_nmatch, hipStream_t s);
 size_t orbx_search_init_lds_bytes(int cap0);
 hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_desc, const int *d_counts, int max_kp,
                                    int npairs, int cap0, float min_x, float max_x, float min_y, float max_y,

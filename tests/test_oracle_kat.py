@@ -259,3 +259,46 @@ def test_three_maxima_and_ratio(oracle):
     assert oracle.lib().orc_ratio_accept(50, 67, 50, 0.75) == 1
     assert oracle.lib().orc_ratio_accept(51, 200, 50, 0.75) == 0
     assert oracle.lib().orc_ratio_accept(30, 40, 50, 0.75) == 0   # 30 < 0.75*40 = 30 is false
+
+
+def test_stereo_matches_known_answer(oracle):
+    """Frame::ComputeStereoMatches on a hand-built case: one left keypoint, two right candidates (the
+    farther descriptor loses), the right image = the left shifted by 8 px and the right keypoint 2 px
+    off, so the window search must land on +2; the sub-pixel offset and the depth are recomputed here
+    from the three window distances in float32.  (A single match at window distance 0 would be removed by
+    the median rule, 0 < 1.5*1.4*0 being false, so the right image carries a little noise.)"""
+    rng = np.random.default_rng(11)
+    w, h = 200, 100
+    wide = rng.integers(0, 256, size=(h, w + 8), dtype=np.uint8)
+    left, right = wide[:, :w].copy(), wide[:, 8:].copy()      # right[x] = left[x + 8]
+    right = np.clip(right.astype(np.int16) + rng.integers(-1, 2, size=right.shape), 0, 255).astype(np.uint8)
+    KP = oracle.KEYPOINT_DTYPE
+    kl = np.zeros(1, KP)
+    kl["x"], kl["y"], kl["octave"] = 100.0, 50.0, 0
+    kr = np.zeros(3, KP)
+    kr["x"] = [90.0, 60.0, 90.0]
+    kr["y"] = [50.4, 50.0, 70.0]          # the third one lies outside the row band
+    kr["octave"] = 0
+    dl = rng.integers(0, 256, size=(1, 32), dtype=np.uint8)
+    dr = np.repeat(dl, 3, axis=0)
+    dr[0, 0] ^= 0x0F                       # distance 4
+    dr[1, :2] ^= 0xFF                      # distance 16
+    sf = np.ones(1, np.float32)
+    mb, mbf = np.float32(0.5), np.float32(40.0)   # maxD = 80
+    n, ur, dp, sad = oracle.compute_stereo_matches(kl, dl, kr, dr, [left], [right], sf, sf, float(mb), float(mbf))
+    assert n == 1
+
+    def window_dist(inc):
+        a = left[45:56, 95:106].astype(np.int32) - int(left[50, 100])
+        b = right[45:56, 85 + inc:96 + inc].astype(np.int32) - int(right[50, 90 + inc])
+        return np.float32(np.abs(a - b).sum())
+
+    d1, d2, d3 = window_dist(1), window_dist(2), window_dist(3)
+    assert sad[0] == int(d2) and 0 < d2 < min(d1, d3)
+    delta = (d1 - d3) / (np.float32(2.0) * (d1 + d3 - np.float32(2.0) * d2))
+    best_ur = np.float32(1.0) * (np.float32(90.0) + np.float32(2.0) + delta)
+    assert ur[0] == best_ur
+    assert dp[0] == mbf / (np.float32(100.0) - best_ur)
+    # a disparity outside [0, mbf/mb) is rejected: with mbf/mb = 4 the match disappears
+    n, ur, dp, _ = oracle.compute_stereo_matches(kl, dl, kr, dr, [left], [right], sf, sf, 10.0, 40.0)
+    assert n == 0 and ur[0] == -1 and dp[0] == -1
