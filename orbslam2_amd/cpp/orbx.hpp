@@ -81,6 +81,7 @@ public:
     std::vector<float> GetScaleSigmaSquares() const { return sigma2_; }
     std::vector<float> GetInverseScaleSigmaSquares() const { return inv_sigma2_; }
     orbx_extractor *handle() { return h_; }
+    int max_keypoints() const { return cap_; }
 
 private:
     orbx_extractor *h_ = nullptr;
@@ -91,5 +92,22 @@ private:
 };
 
 inline int descriptor_distance(const uint8_t *a, const uint8_t *b) { return orbx_descriptor_distance(a, b); }
+
+// Frame::ComputeStereoMatches (src/Frame.cc:534-708) on the images the two extractors processed last:
+// fills mvuRight / mvDepth (one entry per left keypoint, -1 where unmatched), returns the match count.
+inline int compute_stereo_matches(Extractor &left, Extractor &right, float mb, float mbf, std::vector<float> &uright,
+                                  std::vector<float> &depth)
+{
+    const int cap = left.max_keypoints();
+    uright.assign(cap, -1.0f);
+    depth.assign(cap, -1.0f);
+    int n = 0;
+    const int nm = orbx_compute_stereo_matches(left.handle(), right.handle(), 0, mb, mbf, uright.data(), depth.data(),
+                                               cap, &n);
+    check(nm, "orbx_compute_stereo_matches");
+    uright.resize(n);
+    depth.resize(n);
+    return nm;
+}
 
 }  // namespace orbx

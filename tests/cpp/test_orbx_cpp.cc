@@ -32,8 +32,24 @@ int main(int argc, char **argv)
         mix(desc.data(), desc.size());
         int pw, ph;
         std::vector<uint8_t> lvl = ex.pyramid_level(1, 19, pw, ph);
-        printf("OK n=%zu fnv=%016llx levels=%d scale1=%.9g padded=%dx%d d01=%d\n", kps.size(), sum, ex.GetLevels(),
-               ex.GetScaleFactors()[1], pw, ph, orbx::descriptor_distance(desc.data(), desc.data() + 32));
+        // a stereo pair: the right image is the left one shifted by 16 pixels
+        std::vector<uint8_t> right((size_t)w * h);
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++)
+                right[(size_t)y * w + x] = img[(size_t)y * w + (x + 16 < w ? x + 16 : w - 1)];
+        orbx::Extractor exr(1000, 1.2f, 8, 20, 7, w, h);
+        std::vector<orbx_keypoint> kr;
+        std::vector<uint8_t> dr;
+        exr(right.data(), w, h, w, kr, dr);
+        std::vector<float> ur, depth;
+        const int nm = orbx::compute_stereo_matches(ex, exr, 0.537f, 386.1448f, ur, depth);
+        int near16 = 0;
+        for (size_t i = 0; i < ur.size(); i++)
+            if (ur[i] >= 0 && kps[i].x - ur[i] > 15.5f && kps[i].x - ur[i] < 16.5f)
+                near16++;
+        printf("OK n=%zu fnv=%016llx levels=%d scale1=%.9g padded=%dx%d d01=%d stereo=%d near16=%d\n", kps.size(), sum,
+               ex.GetLevels(), ex.GetScaleFactors()[1], pw, ph, orbx::descriptor_distance(desc.data(), desc.data() + 32),
+               nm, near16);
     } catch (const orbx::Error &e) {
         printf("FAIL %s\n", e.what());
         return 1;

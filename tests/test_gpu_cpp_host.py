@@ -34,3 +34,12 @@ def test_cpp_host_layer_matches_python_binding():
     assert int(fields["fnv"], 16) == fnv(kps, desc)
     assert fields["levels"] == "8" and fields["padded"] == "%dx%d" % (533 + 38, 400 + 38)
     assert int(fields["d01"]) == orbx.ORBmatcher.DescriptorDistance(desc[0], desc[1])
+    # the stereo pair of the program (right = left shifted by 16 px) through the Python binding
+    right = np.concatenate([img[:, 16:], np.repeat(img[:, -1:], 16, axis=1)], axis=1)
+    exr = orbx.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    exr(right)
+    nm, ur, _ = orbx.ComputeStereoMatches(ex, exr, 0.537, 386.1448)
+    assert int(fields["stereo"]) == nm and nm > 200
+    d = kps["x"] - ur
+    assert int(fields["near16"]) == int(((ur >= 0) & (d > 15.5) & (d < 16.5)).sum())
+    assert abs(np.median(d[ur >= 0]) - 16) < 1.0
