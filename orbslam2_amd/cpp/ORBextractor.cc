@@ -35,6 +35,8 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
 
 ORBextractor::~ORBextractor() {}
 
+orbx_extractor *ORBextractor::handle() { return impl_ ? impl_->handle() : nullptr; }
+
 void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint> &_keypoints,
                               cv::OutputArray _descriptors)
 {

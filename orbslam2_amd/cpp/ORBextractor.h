@@ -39,6 +39,10 @@ public:
     // (read by Frame::ComputeStereoMatches, src/Frame.cc:541,631,643,648).
     std::vector<cv::Mat> mvImagePyramid;
 
+    // The C-ABI handle behind this extractor (null before the first image): lets
+    // Frame::ComputeStereoMatches call orbx_compute_stereo_matches on what both extractors hold on the GPU.
+    struct orbx_extractor *handle();
+
 protected:
     int nfeatures;
     double scaleFactor;
