@@ -127,6 +127,8 @@ struct FastArgs {
     uint32_t wc_magic[ORBX_MAX_LEVELS], hc_magic[ORBX_MAX_LEVELS];  // ceil(2^20 / cell size)
 };
 
+extern "C" __device__ int __ockl_wfscan_add_i32(int, bool);  // wave-wide prefix sum (device library)
+
 __device__ __forceinline__ int lanes_below(unsigned long long m)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[IMG_H * IMG_W];  // staged pixels
     __shared__ __attribute__((aligned(16))) uint8_t sc[IMG_H * IMG_W];   // A where it exceeds t_low, else 0 (staged coordinates)
-    __shared__ uint16_t queue[QUEUE_CAP + 64];  // pixels that passed the compass test: staged row<<7 | staged column
-    __shared__ int qn, sn;                      // (the last 64 entries take the stores of lanes with nothing to queue)
+    __shared__ uint16_t queue[QUEUE_CAP];  // pixels that passed the compass test: staged row<<7 | staged column
+    __shared__ int qn, sn;
 
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
@@ -213,10 +215,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
                 if (xg + o < x_lo || xg + o >= x_hi)
                     gmask &= ~(0x80u << (8 * o));
         }
-        for (int k = 0; k < 5; k++) {  // every lane of the wave makes every trip: the ballots below need that
+        // Pass bits of the five trips collect in one word: trip k's bits (7, 15, 23, 31) move down by k.
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
             const int r = r0 + 3 + 14 * k;
             const int y = ty0 - 4 + r;
-            uint32_t pass = 0;
             if (walker && r < 3 + SC_H) {
                 const uint32_t *wrow = img32 + r * IMG_WORDS + GRP_0 + g;
                 sc32[r * IMG_WORDS + GRP_0 + g] = 0u;
@@ -230,25 +234,25 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
                     const uint32_t m1 = compass2(widen_hi(vw), widen_hi(dnw), widen_hi(upw), widen_hi(r4w),
                                                  widen_hi(r12w), tt);
                     // sign bytes of the four halves, in pixel order
-                    pass = __builtin_amdgcn_perm(m1, m0, 0x07050301u) & gmask;
+                    acc |= (__builtin_amdgcn_perm(m1, m0, 0x07050301u) & gmask) >> k;
                 }
             }
-            // queue slots: bit o of all lanes first, lanes in order (any one-to-one assignment would do)
-            const unsigned long long b0 = __ballot(pass & 0x80u), b1 = __ballot(pass & 0x8000u);
-            const unsigned long long b2 = __ballot(pass & 0x800000u), b3 = __ballot(pass & 0x80000000u);
-            const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
-            const int total = n0 + n1 + n2 + n3;
-            if (total) {
-                int base = 0;
-                if (lane == 0)
-                    base = atomicAdd(&qn, total);
-                base = __builtin_amdgcn_readfirstlane(base);
-                const uint32_t e = (uint32_t)(r << 7) | (uint32_t)(4 * (GRP_0 + g));
-                const int dump = QUEUE_CAP + lane;
-                queue[(pass & 0x80u) ? base + lanes_below(b0) : dump] = (uint16_t)e;
-                queue[(pass & 0x8000u) ? base + n0 + lanes_below(b1) : dump] = (uint16_t)(e + 1);
-                queue[(pass & 0x800000u) ? base + n0 + n1 + lanes_below(b2) : dump] = (uint16_t)(e + 2);
-                queue[(pass & 0x80000000u) ? base + n0 + n1 + n2 + lanes_below(b3) : dump] = (uint16_t)(e + 3);
+        }
+        // queue slots: a wave-wide prefix sum of the per-lane counts, one LDS atomic per wave
+        const int cnt = __popc(acc);
+        const int incl = __ockl_wfscan_add_i32(cnt, true);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total) {
+            int base = 0;
+            if (lane == 0)
+                base = atomicAdd(&qn, total);
+            int slot = __builtin_amdgcn_readfirstlane(base) + incl - cnt;
+            const uint32_t e0 = (uint32_t)((r0 + 3) << 7) | (uint32_t)(4 * (GRP_0 + g));
+            while (acc) {
+                const int p = __builtin_ctz(acc);   // bit 8o + 7 - k: pixel o of trip k
+                const int k = 7 - (p & 7);
+                queue[slot++] = (uint16_t)(e0 + (uint32_t)(k * (14 << 7)) + (uint32_t)(p >> 3));
+                acc &= acc - 1;
             }
         }
     }
