@@ -84,20 +84,36 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     } else {
         // edge tile: rows and columns outside the image mirror about the border pixel (reflect 101);
         // words that lie inside the row are still loaded whole.  Only words 3 .. 36 of a staged row
-        // (columns tx0-4 .. tx0+131) are needed.
-        for (int i = threadIdx.x; i < BL_SH * 34; i += 256) {
-            const int r = i / 34, c4 = i % 34;
-            const int y = reflect101(ty0 - 3 + r, h), x0 = tx0 - 4 + c4 * 4;
-            const uint8_t *row = src + (size_t)y * spitch;
-            uint32_t v;
-            if (x0 >= 0 && x0 + 3 < w)
-                v = *reinterpret_cast<const uint32_t *>(row + x0);
-            else if (x0 - 3 >= w + 3)
-                v = 0;  // right of every needed column
-            else
-                v = (uint32_t)row[reflect101(x0, w)] | ((uint32_t)row[reflect101(x0 + 1, w)] << 8) |
-                    ((uint32_t)row[reflect101(x0 + 2, w)] << 16) | ((uint32_t)row[reflect101(x0 + 3, w)] << 24);
-            img[r * BL_SWORDS + 3 + c4] = v;
+        // (columns tx0-4 .. tx0+131) are needed.  A thread keeps one word column, so the column's
+        // reflected byte offsets are computed once, and walks down the rows.
+        const int c4 = threadIdx.x & 63;
+        if (c4 < 34) {
+            const int x0 = tx0 - 4 + c4 * 4;
+            const bool whole = x0 >= 0 && x0 + 3 < w;
+            const bool unused = x0 >= w + 3;  // right of every needed column
+            const int o0 = whole ? x0 : reflect101(x0, w), o1 = reflect101(x0 + 1, w);
+            const int o2 = reflect101(x0 + 2, w), o3 = reflect101(x0 + 3, w);
+            // all loads of the thread's rows are issued before the first store
+            uint32_t v[(BL_SH + 3) / 4];
+#pragma unroll
+            for (int k = 0; k < (BL_SH + 3) / 4; k++) {
+                const int r = (threadIdx.x >> 6) + 4 * k;
+                v[k] = 0;
+                if (r < BL_SH && !unused) {
+                    const uint8_t *row = src + (size_t)reflect101(ty0 - 3 + r, h) * spitch;
+                    if (whole)
+                        v[k] = *reinterpret_cast<const uint32_t *>(row + o0);
+                    else
+                        v[k] = (uint32_t)row[o0] | ((uint32_t)row[o1] << 8) | ((uint32_t)row[o2] << 16) |
+                               ((uint32_t)row[o3] << 24);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (BL_SH + 3) / 4; k++) {
+                const int r = (threadIdx.x >> 6) + 4 * k;
+                if (r < BL_SH)
+                    img[r * BL_SWORDS + 3 + c4] = v[k];
+            }
         }
     }
     __syncthreads();
