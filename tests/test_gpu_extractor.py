@@ -299,3 +299,26 @@ def test_scale_tables_match_oracle(oracle):
         kg, dg = e2(img)
         ko, do = oracle_extract(oracle, img, p)
         compare_frame(kg, dg, ko, do)
+
+
+def test_large_image_and_wide_scale_steps(oracle):
+    """Full-HD frame with many features (level 0 exceeds the register-cached quadtree path), and scale
+    factors whose resize takes the widest source windows (2.0) and the byte-wise path (2.6)."""
+    p = dict(nfeatures=5000, scale=1.2, nlevels=8, ini=20, minth=7)
+    img = orbx.synth_image(SEED + 21, 1920, 1080, 0)
+    ex = make_extractor(p, 1920, 1080)
+    kg, dg = ex(img)
+    ko, do = oracle_extract(oracle, img, p)
+    compare_frame(kg, dg, ko, do)
+    assert len(kg) >= 5000
+    ex.close()
+    for sc, nl in [(2.0, 4), (2.6, 3)]:
+        p = dict(nfeatures=1500, scale=sc, nlevels=nl, ini=20, minth=7)
+        img = orbx.synth_image(SEED + nl, 1280, 720, 0)
+        e2 = make_extractor(p, 1280, 720)
+        kg, dg = e2(img)
+        ko, do, tr = oracle_extract(oracle, img, p, trace=True)
+        for l in range(nl):
+            assert np.array_equal(e2.pyramid_level(0, l), tr["levels"][l]), (sc, l)
+        compare_frame(kg, dg, ko, do)
+        e2.close()
