@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
                                                       float *__restrict__ depth, int *__restrict__ sad, StereoArgs a)
 {
     __shared__ int part[4][11][12];  // per wave: window distance of (shift, row)
+    __shared__ float s_rad[ORBX_MAX_LEVELS];  // 2 * scale factor of a level: the row radius of a right keypoint
     const int f = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < ORBX_MAX_LEVELS)
+        s_rad[threadIdx.x] = threadIdx.x < (unsigned)a.nlevels ? 2.0f * a.sf[threadIdx.x] : 0.f;
+    __syncthreads();
     const int iL = blockIdx.x * 4 + wv;
     if (iL >= a.out_cap)
         return;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
             for (int c = c_lo + lane; c < c_hi; c += 64) {
                 const int iR = so[c];
                 const orbx_keypoint r = kr[iR];
-                const float rad = 2.0f * a.sf[r.octave];
+                const float rad = s_rad[r.octave];
                 const int maxr = (int)ceilf(r.y + rad), minr = (int)floorf(r.y - rad);
                 if (row < minr || row > maxr || r.octave < levelL - 1 || r.octave > levelL + 1)
                     continue;
@@ -165,16 +169,18 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                // every lane folds the 11 sums (uniform result)
+                // lane s folds the 11 row sums of shift s; the 11 totals then go to every lane
+                int tot = 0;
+                if (lane < 11) {
+#pragma unroll
+                    for (int r = 0; r < 11; r++)
+                        tot += part[wv][lane][r];
+                }
                 float vDists[11];
                 int bestD = INT_MAX, bestinc = 0;
 #pragma unroll
                 for (int s = 0; s < 11; s++) {
-                    int acc = 0;
-#pragma unroll
-                    for (int r = 0; r < 11; r++)
-                        acc += part[wv][s][r];
-                    const float dist = (float)acc;
+                    const float dist = (float)__builtin_amdgcn_readlane(tot, s);
                     if (dist < (float)bestD) {
                         bestD = (int)dist;
                         bestinc = s - L;
