@@ -244,6 +244,18 @@ int orbx_search_for_initialization_batch_device(orbx_matcher *m, const orbx_keyp
                                                 int check_orientation, int32_t *d_matches12, int32_t *d_nmatches,
                                                 int32_t *d_pair_counts);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:248-319) for npoints map points at once.
+ * The descriptors observed for point p are rows seg_start[p] .. seg_start[p+1]-1 of `descriptors`
+ * (32 bytes each, in the order the caller collected them; the reference walks a
+ * std::map<KeyFrame*, size_t>, i.e. pointer order).  best_idx[p] receives the index inside the segment
+ * of the descriptor with the least median distance to all of the segment (first index on ties), -1 for
+ * an empty segment; best_desc (may be NULL) receives that descriptor.  The _device form takes device
+ * pointers and is asynchronous on the matcher's stream. */
+int orbx_distinctive_descriptors_device(orbx_matcher *m, const uint8_t *d_descriptors, const int32_t *d_seg_start,
+                                        int npoints, int32_t *d_best_idx, uint8_t *d_best_desc);
+int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *descriptors, const int32_t *seg_start, int npoints,
+                                 int32_t *best_idx, uint8_t *best_desc);
+
 /* ---------------------------------------------------------------- synthetic input */
 
 /* Deterministic test/benchmark image (splitmix64 stream seeded with `seed`): gray 128 canvas,

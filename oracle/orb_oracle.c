@@ -1289,4 +1289,36 @@ int orc_compute_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL
     return left;
 }
 
+/* ------------------------------------------------------------------ distinctive descriptor */
+
+static int orc_cmp_int(const void *a, const void *b)
+{
+    const int A = *(const int *)a, B = *(const int *)b;
+    return A < B ? -1 : (A > B ? 1 : 0);
+}
+
+/* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:278-318: of the n descriptors observed for
+ * a map point (rows of 32 bytes, in the order the caller collected them), the index of the one
+ * with the least median distance to all of them (the row of distances includes the 0 to itself; the
+ * median is element (int)(0.5*(n-1)) of the sorted row; the first index wins ties).  -1 for n == 0. */
+int orc_distinctive_descriptor(const uint8_t *desc, int n)
+{
+    if (n <= 0)
+        return -1;
+    int *row = (int *)malloc(sizeof(int) * (size_t)n);
+    int best_median = INT_MAX, best_idx = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++)
+            row[j] = i == j ? 0 : orc_popcnt256(desc + (size_t)i * 32, desc + (size_t)j * 32);
+        qsort(row, (size_t)n, sizeof(int), orc_cmp_int);
+        const int median = row[(int)(0.5 * (n - 1))];
+        if (median < best_median) {
+            best_median = median;
+            best_idx = i;
+        }
+    }
+    free(row);
+    return best_idx;
+}
+
 int orc_trace_sizeof(void) { return (int)sizeof(orc_trace); }

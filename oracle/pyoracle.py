@@ -272,3 +272,12 @@ def compute_stereo_matches(kL, dL, kR, dR, pyrL, pyrR, sf, inv, mb, mbf):
     n = fn(_p(kL), _p(dL), len(kL), _p(kR), _p(dR), len(kR), PT(*[a.ctypes.data for a in pl]),
            PT(*[a.ctypes.data for a in pr]), lw, lh, ls_l, ls_r, nl, _p(sf), _p(inv), mb, mbf, _p(ur), _p(dp), _p(sad))
     return n, ur, dp, sad
+
+
+def distinctive_descriptor(desc):
+    """MapPoint::ComputeDistinctiveDescriptors on an (n, 32) uint8 array: index of the chosen row."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    fn = lib().orc_distinctive_descriptor
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int]
+    return fn(_p(desc), desc.shape[0])

@@ -137,3 +137,111 @@ hipError_t orbx_launch_pair_dist(const uint8_t *d_a, const uint8_t *d_b, const i
                                                 reinterpret_cast<const int2 *>(d_pairs), n, d_out);
     return hipGetLastError();
 }
+
+// ---- MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:278-318) for many map points ----
+// One wave per map point.  Segment p holds the n descriptors observed for the point; lane i owns row i
+// of the distance matrix (rows i, i+64, ... for larger segments): the database side of a distance is
+// the same row for every lane, so it arrives by scalar loads.  The median of a row is its element
+// (int)(0.5*(n-1)) in sorted order = the smallest v with  #(d <= v) > that index, found by a 9-step
+// binary search over the possible distances 0..256.  Segments of up to 64 rows keep a lane's row of
+// distances in registers; larger ones recompute the distances in every search step.
+template <bool SMALL>
+__device__ __forceinline__ uint32_t distinctive_row_median(const uint32_t *__restrict__ seg, int n, int i, int k)
+{
+    uint32_t a[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+        a[w] = seg[(size_t)min(i, n - 1) * 8 + w];
+    int lo = 0, hi = 256;  // the answer lies in [lo, hi]
+    if constexpr (SMALL) {
+        uint32_t d[64];
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            d[j] = 0xffffu;
+            if (j < n) {  // uniform
+                const uint32_t *r = seg + (size_t)j * 8;
+                uint32_t s = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++)
+                    s += __popc(a[w] ^ r[w]);
+                d[j] = s;
+            }
+        }
+#pragma unroll 1
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < 64; j++)
+                c += d[j] <= (uint32_t)mid;
+            if (c > k)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+    } else {
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int c = 0;
+            for (int j = 0; j < n; j++) {
+                const uint32_t *r = seg + (size_t)j * 8;
+                uint32_t s = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++)
+                    s += __popc(a[w] ^ r[w]);
+                c += s <= (uint32_t)mid;
+            }
+            if (c > k)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+    }
+    return (uint32_t)lo;
+}
+
+extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);
+
+__global__ __launch_bounds__(64) void k_distinctive(const uint32_t *__restrict__ desc, const int *__restrict__ seg_start,
+                                                    int npoints, int32_t *__restrict__ best_idx,
+                                                    uint32_t *__restrict__ best_desc)
+{
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int s0 = seg_start[p], n = seg_start[p + 1] - s0;
+    if (n <= 0) {
+        if (lane == 0)
+            best_idx[p] = -1;
+        return;
+    }
+    const uint32_t *seg = desc + (size_t)s0 * 8;
+    const int k = (int)(0.5 * (n - 1));
+    uint32_t best = 0xffffffffu;  // median << 20 | row: the first row with the least median wins
+    if (n <= 64) {
+        const uint32_t m = distinctive_row_median<true>(seg, n, lane, k);
+        if (lane < n)
+            best = (m << 20) | (uint32_t)lane;
+    } else {
+        for (int i0 = 0; i0 < n; i0 += 64) {  // uniform trips
+            const int i = i0 + lane;
+            const uint32_t m = distinctive_row_median<false>(seg, n, i, k);
+            if (i < n)
+                best = min(best, (m << 20) | (uint32_t)i);
+        }
+    }
+    best = __ockl_wfred_min_u32(best);
+    const int bi = (int)(best & 0xfffffu);
+    if (lane == 0)
+        best_idx[p] = bi;
+    if (best_desc && lane < 8)
+        best_desc[(size_t)p * 8 + lane] = seg[(size_t)bi * 8 + lane];
+}
+
+hipError_t orbx_launch_distinctive(const uint8_t *d_desc, const int *d_seg_start, int npoints, int32_t *d_best_idx,
+                                   uint8_t *d_best_desc, hipStream_t s)
+{
+    if (npoints <= 0)
+        return hipSuccess;
+    k_distinctive<<<npoints, 64, 0, s>>>(reinterpret_cast<const uint32_t *>(d_desc), d_seg_start, npoints, d_best_idx,
+                                         reinterpret_cast<uint32_t *>(d_best_desc));
+    return hipGetLastError();
+}

@@ -925,6 +925,9 @@ struct orbx_matcher {
     int *d_pairs;
     uint16_t *d_pd;
     size_t a_cap, b_cap, pairs_cap;
+    // segment starts and results of the distinctive-descriptor call
+    int *d_seg;
+    size_t seg_cap;
 };
 
 extern "C" int orbx_matcher_create(int device, int max_queries, orbx_matcher **out)
@@ -963,7 +966,8 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     (void)hipSetDevice(m->device);
     if (m->stream)
         (void)hipStreamSynchronize(m->stream);
-    void *ptrs[] = {m->d_partial, m->d_q, m->d_db, m->d_best, m->d_d1, m->d_d2, m->d_a, m->d_b, m->d_pairs, m->d_pd};
+    void *ptrs[] = {m->d_partial, m->d_q, m->d_db, m->d_best, m->d_d1, m->d_d2, m->d_a, m->d_b, m->d_pairs, m->d_pd,
+                    m->d_seg};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -1397,6 +1401,47 @@ extern "C" int orbx_search_for_initialization_batch_device(orbx_matcher *m, cons
     HIP_TRY(orbx_launch_search_init(d_keypoints, d_descriptors, d_counts, max_keypoints, nframes - 1, max_level0, min_x,
                                     max_x, min_y, max_y, d_prev_matched, d_prev_matched_out, window_size, nnratio,
                                     check_orientation, d_matches12, d_nmatches, d_pair_counts, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_distinctive_descriptors_device(orbx_matcher *m, const uint8_t *d_descriptors,
+                                                   const int32_t *d_seg_start, int npoints, int32_t *d_best_idx,
+                                                   uint8_t *d_best_desc)
+{
+    if (!m || npoints < 0 || (npoints > 0 && (!d_descriptors || !d_seg_start || !d_best_idx)))
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(orbx_launch_distinctive(d_descriptors, d_seg_start, npoints, d_best_idx, d_best_desc, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *descriptors, const int32_t *seg_start,
+                                            int npoints, int32_t *best_idx, uint8_t *best_desc)
+{
+    if (!m || npoints < 0 || (npoints > 0 && (!descriptors || !seg_start || !best_idx)))
+        return ORBX_E_ARG;
+    if (npoints == 0)
+        return ORBX_OK;
+    const int64_t rows = seg_start[npoints];
+    for (int p = 0; p < npoints; p++)
+        if (seg_start[p] < 0 || seg_start[p + 1] < seg_start[p])
+            return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    // workspace: descriptors in d_db, segment starts and results in d_seg, chosen descriptors in d_a
+    int rc = grow(&m->d_db, &m->db_cap, (size_t)std::max<int64_t>(rows, 1) * 32, m->stream);
+    if (rc == ORBX_OK) rc = grow(&m->d_seg, &m->seg_cap, (size_t)2 * npoints + 2, m->stream);
+    if (rc == ORBX_OK) rc = grow(&m->d_a, &m->a_cap, (size_t)npoints * 32, m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    int *d_seg = m->d_seg, *d_best = m->d_seg + npoints + 1;
+    if (rows > 0)
+        HIP_TRY(hipMemcpyAsync(m->d_db, descriptors, (size_t)rows * 32, hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipMemcpyAsync(d_seg, seg_start, sizeof(int) * (size_t)(npoints + 1), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(orbx_launch_distinctive(m->d_db, d_seg, npoints, d_best, best_desc ? m->d_a : nullptr, m->stream));
+    HIP_TRY(hipMemcpyAsync(best_idx, d_best, sizeof(int) * (size_t)npoints, hipMemcpyDeviceToHost, m->stream));
+    if (best_desc)
+        HIP_TRY(hipMemcpyAsync(best_desc, m->d_a, (size_t)npoints * 32, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
     return ORBX_OK;
 }
 

@@ -133,6 +133,8 @@ hipError_t orbx_launch_top2(const uint8_t *d_q, int nq, const uint8_t *d_db, int
 hipError_t orbx_launch_stereo(const OrbxGeom &g, const OrbxBuffers &bl, const OrbxBuffers &br, const float *sf,
                               const float *inv, float mb, float mbf, int *d_rowstart, uint16_t *d_sorted, int *d_sad,
                               float *d_uright, float *d_depth, int *d_nmatch, hipStream_t s);
+hipError_t orbx_launch_distinctive(const uint8_t *d_desc, const int *d_seg_start, int npoints, int32_t *d_best_idx,
+                                   uint8_t *d_best_desc, hipStream_t s);
 size_t orbx_search_init_lds_bytes(int cap0);
 hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_desc, const int *d_counts, int max_kp,
                                    int npairs, int cap0, float min_x, float max_x, float min_y, float max_y,

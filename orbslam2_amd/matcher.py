@@ -126,3 +126,17 @@ class ORBmatcher:
             bounds[1], bounds[2], bounds[3], d_prev_matched, d_prev_matched_out, windowSize, self.mfNNratio,
             int(self.mbCheckOrientation), d_matches12, d_nmatches, d_pair_counts),
             "orbx_search_for_initialization_batch_device")
+
+    def ComputeDistinctiveDescriptors(self, segments):
+        """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:248-319) for a list of map points:
+        segments[p] is the (n_p, 32) uint8 array of the descriptors observed for point p.
+        Returns (best index per point, -1 for an empty one; (npoints, 32) chosen descriptors)."""
+        segs = [np.ascontiguousarray(s, np.uint8).reshape(-1, 32) for s in segments]
+        start = np.zeros(len(segs) + 1, np.int32)
+        start[1:] = np.cumsum([len(s) for s in segs])
+        rows = np.concatenate(segs) if segs and start[-1] > 0 else np.zeros((1, 32), np.uint8)
+        best = np.zeros(len(segs), np.int32)
+        out = np.zeros((len(segs), 32), np.uint8)
+        L.check(self._lib.orbx_distinctive_descriptors(self._handle(), L.ptr(rows), L.ptr(start), len(segs),
+                                                       L.ptr(best), L.ptr(out)), "orbx_distinctive_descriptors")
+        return best, out

@@ -201,3 +201,29 @@ def test_search_for_initialization_batch_device_vs_oracle(oracle, ratio, ori, wi
                                              nmb.data_ptr(), npb.data_ptr(), windowSize=win)
     torch.cuda.synchronize()
     assert nmb.cpu().numpy()[0] == -3  # ORBX_E_CAPACITY
+
+
+def test_distinctive_descriptors_vs_oracle(oracle):
+    """Segments of 0 .. 200 observations: noisy copies of a base descriptor (so medians tie often) and
+    unrelated rows; the chosen index and descriptor must equal the oracle's."""
+    rng = np.random.default_rng(9)
+    segs = []
+    for n in [0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 63, 64, 65, 100, 200, 4, 4, 7]:
+        base = rng.integers(0, 256, size=32, dtype=np.uint8)
+        rows = np.repeat(base[None], n, axis=0)
+        for i in range(n):
+            bits = np.unpackbits(rows[i])
+            bits[rng.choice(256, size=int(rng.integers(0, 12)), replace=False)] ^= 1
+            rows[i] = np.packbits(bits)
+            if i % 7 == 6:
+                rows[i] = rng.integers(0, 256, size=32, dtype=np.uint8)   # an outlier observation
+        segs.append(rows)
+    segs.append(np.repeat(rng.integers(0, 256, size=(1, 32), dtype=np.uint8), 9, axis=0))  # all equal: index 0
+    m = orbx.ORBmatcher()
+    best, out = m.ComputeDistinctiveDescriptors(segs)
+    for p, rows in enumerate(segs):
+        want = oracle.distinctive_descriptor(rows)
+        assert best[p] == want, (p, len(rows))
+        if want >= 0:
+            assert np.array_equal(out[p], rows[want])
+    assert best[0] == -1 and best[-1] == 0

@@ -302,3 +302,20 @@ def test_stereo_matches_known_answer(oracle):
     # a disparity outside [0, mbf/mb) is rejected: with mbf/mb = 4 the match disappears
     n, ur, dp, _ = oracle.compute_stereo_matches(kl, dl, kr, dr, [left], [right], sf, sf, 10.0, 40.0)
     assert n == 0 and ur[0] == -1 and dp[0] == -1
+
+
+def test_distinctive_descriptor_known_answer(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors by hand: rows A, B = A with 2 bits flipped, C = A with 2
+    other bits flipped, D = all different.  Distances from A: 0,2,2,256 -> sorted 0,2,2,256, median index
+    (int)(0.5*3) = 1 -> 2; from B: 0,2,4,254 -> 2; from C: 0,2,4,254 -> 2; from D: 0,254,254,256 -> 254.
+    The first row with the least median (A) wins."""
+    a = np.zeros(32, np.uint8)
+    b, c = a.copy(), a.copy()
+    b[0] = 0x03
+    c[1] = 0x03
+    d = np.full(32, 0xFF, np.uint8)
+    assert oracle.distinctive_descriptor(np.stack([a, b, c, d])) == 0
+    assert oracle.distinctive_descriptor(np.stack([d, a, b, c])) == 1
+    # two rows: the median index is (int)(0.5*1) = 0, the distance of a row to itself: index 0 wins
+    assert oracle.distinctive_descriptor(np.stack([d, a])) == 0
+    assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1

@@ -24,4 +24,6 @@ cd $REPO
 timeout -k 10 200 python3 tools/pcie_rate.py > "$OUT/pcie_rate.log" 2>/dev/null || exit 1
 timeout -k 10 200 python3 tools/latency_breakdown.py > "$OUT/latency_breakdown.log" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/config5_pairs.py > "$OUT/config5_pairs.json" 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/stereo_rate.py > "$OUT/stereo_rate.json" 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/distinctive_rate.py > "$OUT/distinctive_rate.json" 2>/dev/null || exit 1
 echo collected
