@@ -244,6 +244,28 @@ int orbx_search_for_initialization_batch_device(orbx_matcher *m, const orbx_keyp
                                                 int check_orientation, int32_t *d_matches12, int32_t *d_nmatches,
                                                 int32_t *d_pair_counts);
 
+/* ORBmatcher::SearchByBoW for nb key frames ("side 1") against one frame or key frame ("side 2"):
+ * src/ORBmatcher.cc:176-311 (key frame against frame: strict_lt = 0, valid2 = NULL; this is what
+ * Tracking::Relocalization runs for every candidate key frame, src/Tracking.cc:1573-1586) and :552-686
+ * (key frame against key frame: strict_lt = 1, valid2 given).  Host arrays in, host arrays out.
+ * Side 1, all key frames concatenated: desc1 (32 bytes per feature), angle1 (keypoint angles),
+ * valid1 (1 = the feature has a usable map point; NULL = all), feat_start[nb+1] (first feature of each
+ * key frame).  Its feature vectors (DBoW2::FeatureVector: node id -> feature indices): the node
+ * entries of all key frames concatenated, node_kf_start[nb+1] (first entry of each key frame),
+ * node_ids1 (ascending inside a key frame), node_start1[entries+1] (offsets into node_items1),
+ * node_items1 (feature indices local to the key frame, in the vector's order).
+ * Side 2: desc2, angle2, valid2 (or NULL), n2 features; node_ids2 (ascending), node_start2[m2+1],
+ * node_items2.  A node may hold at most 4096 features of side 2 (ORBX_E_CAPACITY otherwise).
+ * match12 (one entry per feature of side 1): index into side 2 or -1; match21 (nb x n2): feature
+ * index local to the key frame or -1; nmatches[nb].  The order-dependent greedy pass, the ratio test
+ * and the rotation histogram with its three maxima follow the reference exactly. */
+int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1,
+                       const int32_t *feat_start, int nb, const int32_t *node_kf_start, const int32_t *node_ids1,
+                       const int32_t *node_start1, const int32_t *node_items1, const uint8_t *desc2,
+                       const float *angle2, const uint8_t *valid2, int n2, const int32_t *node_ids2,
+                       const int32_t *node_start2, const int32_t *node_items2, int m2, int strict_lt, float nnratio,
+                       int check_orientation, int32_t *match12, int32_t *match21, int32_t *nmatches);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:248-319) for npoints map points at once.
  * The descriptors observed for point p are rows seg_start[p] .. seg_start[p+1]-1 of `descriptors`
  * (32 bytes each, in the order the caller collected them; the reference walks a

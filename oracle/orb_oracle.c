@@ -1289,6 +1289,93 @@ int orc_compute_stereo_matches(const orc_keypoint *kL, const uint8_t *dL, int nL
     return left;
 }
 
+/* ------------------------------------------------------------------ matching by vocabulary node */
+
+/* ORBmatcher::SearchByBoW, src/ORBmatcher.cc:176-311 (key frame against frame: strict_lt = 0, valid2 =
+ * NULL) and :552-686 (key frame against key frame: strict_lt = 1, valid2 given).  The feature vectors
+ * (DBoW2::FeatureVector, a map node id -> feature indices) are given as ascending node ids with CSR
+ * index lists.  valid1/valid2: the feature has a usable map point.  match12 (n1 entries) / match21
+ * (n2 entries) receive the partner's index or -1.  Returns the number of matches. */
+int orc_search_by_bow(const uint8_t *d1, const float *ang1, const uint8_t *valid1, int n1, const int *ids1,
+                      const int *start1, const int *items1, int m1, const uint8_t *d2, const float *ang2,
+                      const uint8_t *valid2, int n2, const int *ids2, const int *start2, const int *items2, int m2,
+                      int strict_lt, float ratio, int check_ori, int *match12, int *match21)
+{
+    enum { TH_LOW = 50, HISTO = 30 };
+    for (int i = 0; i < n1; i++)
+        match12[i] = -1;
+    for (int i = 0; i < n2; i++)
+        match21[i] = -1;
+    int nmatches = 0;
+    int hist[HISTO] = {0};
+    int *bin_of = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1));
+    for (int i = 0; i < n1; i++)
+        bin_of[i] = -1;
+    const float factor = HISTO / 360.0f;
+    int a = 0, b = 0;
+    while (a < m1 && b < m2) {
+        if (ids1[a] == ids2[b]) {
+            for (int i1 = start1[a]; i1 < start1[a + 1]; i1++) {
+                const int idx1 = items1[i1];
+                if (valid1 && !valid1[idx1])
+                    continue;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = start2[b]; i2 < start2[b + 1]; i2++) {
+                    const int idx2 = items2[i2];
+                    if (match21[idx2] >= 0 || (valid2 && !valid2[idx2]))
+                        continue;
+                    const int dist = orc_popcnt256(d1 + (size_t)idx1 * 32, d2 + (size_t)idx2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = idx2;
+                    } else if (dist < bestDist2)
+                        bestDist2 = dist;
+                }
+                if (strict_lt ? bestDist1 < TH_LOW : bestDist1 <= TH_LOW) {
+                    if ((float)bestDist1 < ratio * (float)bestDist2) {
+                        match12[idx1] = bestIdx2;
+                        match21[bestIdx2] = idx1;
+                        if (check_ori) {
+                            float rot = ang1[idx1] - ang2[bestIdx2];
+                            if (rot < 0.0)
+                                rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO)
+                                bin = 0;
+                            hist[bin]++;
+                            bin_of[idx1] = bin;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            a++;
+            b++;
+        } else if (ids1[a] < ids2[b]) {
+            while (a < m1 && ids1[a] < ids2[b]) /* lower_bound */
+                a++;
+        } else {
+            while (b < m2 && ids2[b] < ids1[a])
+                b++;
+        }
+    }
+    if (check_ori) {
+        int i1m, i2m, i3m;
+        orc_three_maxima(hist, HISTO, &i1m, &i2m, &i3m);
+        for (int i = 0; i < n1; i++) {
+            const int bn = bin_of[i];
+            if (bn < 0 || bn == i1m || bn == i2m || bn == i3m)
+                continue;
+            match21[match12[i]] = -1;
+            match12[i] = -1;
+            nmatches--;
+        }
+    }
+    free(bin_of);
+    return nmatches;
+}
+
 /* ------------------------------------------------------------------ distinctive descriptor */
 
 static int orc_cmp_int(const void *a, const void *b)

@@ -281,3 +281,27 @@ def distinctive_descriptor(desc):
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int]
     return fn(_p(desc), desc.shape[0])
+
+
+def search_by_bow(d1, ang1, valid1, nodes1, d2, ang2, valid2, nodes2, strict_lt, ratio, check_ori):
+    """ORBmatcher::SearchByBoW.  nodes*: (ids, start, items) int32 arrays of a feature vector.
+    Returns (nmatches, match12, match21)."""
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+    ang1 = np.ascontiguousarray(ang1, np.float32)
+    ang2 = np.ascontiguousarray(ang2, np.float32)
+    v1 = None if valid1 is None else np.ascontiguousarray(valid1, np.uint8)
+    v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+    i1, s1, t1 = (np.ascontiguousarray(a, np.int32) for a in nodes1)
+    i2, s2, t2 = (np.ascontiguousarray(a, np.int32) for a in nodes2)
+    m12 = np.zeros(len(d1), np.int32)
+    m21 = np.zeros(len(d2), np.int32)
+    fn = lib().orc_search_by_bow
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                   C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    n = fn(_p(d1), _p(ang1), None if v1 is None else _p(v1), len(d1), _p(i1), _p(s1), _p(t1), len(i1), _p(d2),
+           _p(ang2), None if v2 is None else _p(v2), len(d2), _p(i2), _p(s2), _p(t2), len(i2), int(strict_lt), ratio,
+           int(check_ori), _p(m12), _p(m21))
+    return n, m12, m21

@@ -84,6 +84,8 @@ SIGNATURES = {
     "orbx_compute_stereo_matches_device": (C.c_int, [_P, _P, C.c_float, C.c_float, _P, _P, _P]),
     "orbx_compute_stereo_matches": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int,
                                               C.POINTER(C.c_int)]),
+    "orbx_search_by_bow": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P,
+                                     C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P]),
     "orbx_distinctive_descriptors_device": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     "orbx_distinctive_descriptors": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     "orbx_synth_image": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, _P, C.c_int]),

@@ -928,6 +928,9 @@ struct orbx_matcher {
     // segment starts and results of the distinctive-descriptor call
     int *d_seg;
     size_t seg_cap;
+    // one allocation carved into the arrays of a SearchByBoW call
+    uint8_t *d_ws;
+    size_t ws_cap;
 };
 
 extern "C" int orbx_matcher_create(int device, int max_queries, orbx_matcher **out)
@@ -967,7 +970,7 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     if (m->stream)
         (void)hipStreamSynchronize(m->stream);
     void *ptrs[] = {m->d_partial, m->d_q, m->d_db, m->d_best, m->d_d1, m->d_d2, m->d_a, m->d_b, m->d_pairs, m->d_pd,
-                    m->d_seg};
+                    m->d_seg, m->d_ws};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -1402,6 +1405,83 @@ extern "C" int orbx_search_for_initialization_batch_device(orbx_matcher *m, cons
                                     max_x, min_y, max_y, d_prev_matched, d_prev_matched_out, window_size, nnratio,
                                     check_orientation, d_matches12, d_nmatches, d_pair_counts, m->stream));
     return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1,
+                                  const int32_t *feat_start, int nb, const int32_t *node_kf_start,
+                                  const int32_t *node_ids1, const int32_t *node_start1, const int32_t *node_items1,
+                                  const uint8_t *desc2, const float *angle2, const uint8_t *valid2, int n2,
+                                  const int32_t *node_ids2, const int32_t *node_start2, const int32_t *node_items2,
+                                  int m2, int strict_lt, float nnratio, int check_orientation, int32_t *match12,
+                                  int32_t *match21, int32_t *nmatches)
+{
+    if (!m || nb < 0 || n2 < 0 || m2 < 0 || !feat_start || !node_kf_start || !match12 || !match21 || !nmatches)
+        return ORBX_E_ARG;
+    if (nb == 0)
+        return ORBX_OK;
+    const int F1 = feat_start[nb], E1 = node_kf_start[nb];
+    if (F1 < 0 || E1 < 0 || (F1 > 0 && (!desc1 || !angle1)) || (E1 > 0 && (!node_ids1 || !node_start1 || !node_items1)) ||
+        (n2 > 0 && (!desc2 || !angle2)) || (m2 > 0 && (!node_ids2 || !node_start2 || !node_items2)))
+        return ORBX_E_ARG;
+    const int I1 = E1 > 0 ? node_start1[E1] : 0, I2 = m2 > 0 ? node_start2[m2] : 0;
+    // the key frame of every node entry
+    std::vector<int> node_kf((size_t)std::max(E1, 1));
+    for (int b = 0; b < nb; b++)
+        for (int e = node_kf_start[b]; e < node_kf_start[b + 1]; e++)
+            node_kf[e] = b;
+    HIP_TRY(hipSetDevice(m->device));
+    // carve one workspace: every array starts at a multiple of 256 bytes
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += (std::max<size_t>(bytes, 4) + 255) / 256 * 256;
+        return at;
+    };
+    const size_t o_d1 = carve((size_t)F1 * 32), o_a1 = carve((size_t)F1 * 4), o_v1 = carve((size_t)F1);
+    const size_t o_fs = carve((size_t)(nb + 1) * 4), o_nk = carve((size_t)E1 * 4), o_i1 = carve((size_t)E1 * 4);
+    const size_t o_s1 = carve((size_t)(E1 + 1) * 4), o_t1 = carve((size_t)I1 * 4);
+    const size_t o_d2 = carve((size_t)n2 * 32), o_a2 = carve((size_t)n2 * 4), o_v2 = carve((size_t)n2);
+    const size_t o_i2 = carve((size_t)m2 * 4), o_s2 = carve((size_t)(m2 + 1) * 4), o_t2 = carve((size_t)I2 * 4);
+    const size_t o_m12 = carve((size_t)F1 * 4), o_m21 = carve((size_t)nb * std::max(n2, 1) * 4);
+    const size_t o_nm = carve((size_t)nb * 4), o_bin = carve((size_t)F1), o_h = carve((size_t)nb * 32 * 4);
+    const size_t o_st = carve(4);
+    int rc = grow(&m->d_ws, &m->ws_cap, off, m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    uint8_t *w = m->d_ws;
+    auto up = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(w + at, src, bytes, hipMemcpyHostToDevice, m->stream) : hipSuccess;
+    };
+    HIP_TRY(up(o_d1, desc1, (size_t)F1 * 32));
+    HIP_TRY(up(o_a1, angle1, (size_t)F1 * 4));
+    if (valid1) HIP_TRY(up(o_v1, valid1, (size_t)F1));
+    HIP_TRY(up(o_fs, feat_start, (size_t)(nb + 1) * 4));
+    HIP_TRY(up(o_nk, node_kf.data(), (size_t)E1 * 4));
+    HIP_TRY(up(o_i1, node_ids1, (size_t)E1 * 4));
+    if (E1 > 0) HIP_TRY(up(o_s1, node_start1, (size_t)(E1 + 1) * 4));
+    HIP_TRY(up(o_t1, node_items1, (size_t)I1 * 4));
+    HIP_TRY(up(o_d2, desc2, (size_t)n2 * 32));
+    HIP_TRY(up(o_a2, angle2, (size_t)n2 * 4));
+    if (valid2) HIP_TRY(up(o_v2, valid2, (size_t)n2));
+    HIP_TRY(up(o_i2, node_ids2, (size_t)m2 * 4));
+    if (m2 > 0) HIP_TRY(up(o_s2, node_start2, (size_t)(m2 + 1) * 4));
+    HIP_TRY(up(o_t2, node_items2, (size_t)I2 * 4));
+    HIP_TRY(orbx_launch_bow(w + o_d1, (const float *)(w + o_a1), valid1 ? w + o_v1 : nullptr, (const int *)(w + o_fs), nb,
+                            F1, (const int *)(w + o_nk), (const int *)(w + o_i1), (const int *)(w + o_s1),
+                            (const int *)(w + o_t1), E1, w + o_d2, (const float *)(w + o_a2),
+                            valid2 ? w + o_v2 : nullptr, n2, (const int *)(w + o_i2), (const int *)(w + o_s2),
+                            (const int *)(w + o_t2), m2, strict_lt, nnratio, check_orientation, (int *)(w + o_m12),
+                            (int *)(w + o_m21), (int *)(w + o_nm), (int8_t *)(w + o_bin), (int *)(w + o_h),
+                            (int *)(w + o_st), m->stream));
+    int status = 0;
+    if (F1 > 0)
+        HIP_TRY(hipMemcpyAsync(match12, w + o_m12, (size_t)F1 * 4, hipMemcpyDeviceToHost, m->stream));
+    if (n2 > 0)
+        HIP_TRY(hipMemcpyAsync(match21, w + o_m21, (size_t)nb * n2 * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(nmatches, w + o_nm, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(&status, w + o_st, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return status ? ORBX_E_CAPACITY : ORBX_OK;
 }
 
 extern "C" int orbx_distinctive_descriptors_device(orbx_matcher *m, const uint8_t *d_descriptors,

@@ -135,6 +135,12 @@ hipError_t orbx_launch_stereo(const OrbxGeom &g, const OrbxBuffers &bl, const Or
                               float *d_uright, float *d_depth, int *d_nmatch, hipStream_t s);
 hipError_t orbx_launch_distinctive(const uint8_t *d_desc, const int *d_seg_start, int npoints, int32_t *d_best_idx,
                                    uint8_t *d_best_desc, hipStream_t s);
+hipError_t orbx_launch_bow(const uint8_t *d_desc1, const float *d_ang1, const uint8_t *d_valid1, const int *d_feat_start,
+                           int nb, int total_feat1, const int *d_node_kf, const int *d_ids1, const int *d_start1,
+                           const int *d_items1, int total_nodes1, const uint8_t *d_desc2, const float *d_ang2,
+                           const uint8_t *d_valid2, int n2, const int *d_ids2, const int *d_start2, const int *d_items2,
+                           int m2, int strict_lt, float ratio, int check_ori, int *d_match12, int *d_match21,
+                           int *d_nmatches, int8_t *d_bin_of, int *d_hist, int *d_status, hipStream_t s);
 size_t orbx_search_init_lds_bytes(int cap0);
 hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_desc, const int *d_counts, int max_kp,
                                    int npairs, int cap0, float min_x, float max_x, float min_y, float max_y,

@@ -140,3 +140,49 @@ class ORBmatcher:
         L.check(self._lib.orbx_distinctive_descriptors(self._handle(), L.ptr(rows), L.ptr(start), len(segs),
                                                        L.ptr(best), L.ptr(out)), "orbx_distinctive_descriptors")
         return best, out
+
+    def SearchByBoW(self, keyframes, frame, strict_lt=False):
+        """ORBmatcher::SearchByBoW (src/ORBmatcher.cc:176-311; strict_lt=True with frame["valid"] set is
+        the key-frame-against-key-frame form, :552-686) of a list of key frames against one frame.
+        Every item is a dict: desc (n,32) uint8, angle (n,) float32, valid (n,) bool or None, and the
+        feature vector as node_ids (ascending), node_start, node_items (int32 CSR).
+        Returns (nmatches per key frame, [match12 per key frame], match21 (nb, n2))."""
+        nb = len(keyframes)
+        if nb == 0:
+            return np.zeros(0, np.int32), [], np.zeros((0, len(frame["desc"])), np.int32)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)  # noqa: E731
+        feat_start = np.zeros(nb + 1, np.int32)
+        feat_start[1:] = np.cumsum([len(k["desc"]) for k in keyframes])
+        node_kf_start = np.zeros(nb + 1, np.int32)
+        node_kf_start[1:] = np.cumsum([len(k["node_ids"]) for k in keyframes])
+        cat = lambda key, dt, shape: (np.ascontiguousarray(np.concatenate(  # noqa: E731
+            [np.asarray(k[key], dt).reshape(shape) for k in keyframes]), dt))
+        d1 = cat("desc", np.uint8, (-1, 32))
+        a1 = cat("angle", np.float32, (-1,))
+        has_valid = nb > 0 and keyframes[0].get("valid") is not None
+        v1 = cat("valid", np.uint8, (-1,)) if has_valid else None
+        ids1 = cat("node_ids", np.int32, (-1,))
+        items1 = cat("node_items", np.int32, (-1,))
+        # node_start of every key frame is relative to its own items: shift to the concatenation
+        starts, base = [], 0
+        for k in keyframes:
+            st = i32(k["node_start"])
+            starts.append(st[:-1] + base)
+            base += int(st[-1])
+        start1 = i32(np.concatenate(starts + [np.array([base], np.int32)])) if nb else np.zeros(1, np.int32)
+        d2 = np.ascontiguousarray(frame["desc"], np.uint8).reshape(-1, 32)
+        a2 = np.ascontiguousarray(frame["angle"], np.float32)
+        v2 = None if frame.get("valid") is None else np.ascontiguousarray(frame["valid"], np.uint8)
+        ids2, start2, items2 = i32(frame["node_ids"]), i32(frame["node_start"]), i32(frame["node_items"])
+        n2 = len(d2)
+        m12 = np.zeros(max(len(d1), 1), np.int32)
+        m21 = np.zeros((max(nb, 1), max(n2, 1)), np.int32)
+        nm = np.zeros(max(nb, 1), np.int32)
+        P = lambda a: None if a is None else L.ptr(a)  # noqa: E731
+        L.check(self._lib.orbx_search_by_bow(self._handle(), P(d1), P(a1), P(v1), P(feat_start), nb, P(node_kf_start),
+                                             P(ids1), P(start1), P(items1), P(d2), P(a2), P(v2), n2, P(ids2),
+                                             P(start2), P(items2), len(ids2), int(strict_lt), self.mfNNratio,
+                                             int(self.mbCheckOrientation), P(m12), P(m21), P(nm)),
+                "orbx_search_by_bow")
+        per_kf = [m12[feat_start[b]:feat_start[b + 1]].copy() for b in range(nb)]
+        return nm[:nb].copy(), per_kf, m21[:nb, :n2].copy()

@@ -227,3 +227,67 @@ def test_distinctive_descriptors_vs_oracle(oracle):
         if want >= 0:
             assert np.array_equal(out[p], rows[want])
     assert best[0] == -1 and best[-1] == 0
+
+
+def _feature_vector(words):
+    """DBoW2::FeatureVector of a list of node ids per feature: ascending ids, CSR index lists."""
+    ids = np.unique(words).astype(np.int32)
+    order = np.argsort(words, kind="stable").astype(np.int32)
+    counts = np.array([(words == i).sum() for i in ids], np.int32)
+    start = np.zeros(len(ids) + 1, np.int32)
+    start[1:] = np.cumsum(counts)
+    return ids, start, order
+
+
+def _bow_item(rng, src_desc, src_words, n, noise_bits, valid_frac):
+    """A key frame whose features are noisy copies of random features of the source (with the source's
+    word most of the time), plus unrelated ones."""
+    pick = rng.integers(0, len(src_desc), size=n)
+    desc = src_desc[pick].copy()
+    for i in range(n):
+        bits = np.unpackbits(desc[i])
+        bits[rng.choice(256, size=int(rng.integers(0, noise_bits)), replace=False)] ^= 1
+        desc[i] = np.packbits(bits)
+    words = src_words[pick].copy()
+    wrong = rng.random(n) < 0.1
+    words[wrong] = rng.integers(0, src_words.max() + 1, size=int(wrong.sum()))
+    fresh = rng.random(n) < 0.15
+    desc[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), 32), dtype=np.uint8)
+    ids, start, items = _feature_vector(words)
+    return dict(desc=desc, angle=(rng.random(n) * 360).astype(np.float32), valid=rng.random(n) < valid_frac,
+                node_ids=ids, node_start=start, node_items=items)
+
+
+@pytest.mark.parametrize("strict,ratio,ori", [(False, 0.75, True), (False, 0.7, False), (True, 0.8, True)])
+def test_search_by_bow_vs_oracle(oracle, strict, ratio, ori):
+    rng = np.random.default_rng(21)
+    n2 = 1500
+    d2 = rng.integers(0, 256, size=(n2, 32), dtype=np.uint8)
+    w2 = rng.integers(0, 90, size=n2)
+    w2[:300] = 7          # one crowded vocabulary node: several passes of 64 lanes
+    ids2, start2, items2 = _feature_vector(w2)
+    frame = dict(desc=d2, angle=(rng.random(n2) * 360).astype(np.float32),
+                 valid=(rng.random(n2) < 0.8) if strict else None, node_ids=ids2, node_start=start2,
+                 node_items=items2)
+    kfs = [_bow_item(rng, d2, w2, n, 40, 0.7) for n in (900, 1200, 1, 300)]
+    # angles close to the frame's for most features, so that the rotation histogram has a clear maximum
+    for k in kfs:
+        k["angle"] = ((rng.random(len(k["desc"])) * 20) + 100).astype(np.float32)
+    frame["angle"][:] = 95.0
+    m = orbx.ORBmatcher(ratio, ori)
+    nm, m12, m21 = m.SearchByBoW(kfs, frame, strict_lt=strict)
+    total = 0
+    for b, k in enumerate(kfs):
+        on, o12, o21 = oracle.search_by_bow(k["desc"], k["angle"], k["valid"],
+                                            (k["node_ids"], k["node_start"], k["node_items"]), d2, frame["angle"],
+                                            frame["valid"], (ids2, start2, items2), strict, ratio, ori)
+        assert nm[b] == on
+        assert np.array_equal(m12[b], o12) and np.array_equal(m21[b], o21)
+        total += on
+    assert total > 300
+    # no key frames, and a key frame without features
+    assert len(m.SearchByBoW([], frame)[0]) == 0
+    empty = dict(desc=np.zeros((0, 32), np.uint8), angle=np.zeros(0, np.float32), valid=np.zeros(0, bool),
+                 node_ids=np.zeros(0, np.int32), node_start=np.zeros(1, np.int32), node_items=np.zeros(0, np.int32))
+    nm, m12, m21 = m.SearchByBoW([empty], frame)
+    assert nm[0] == 0 and (m21 == -1).all()

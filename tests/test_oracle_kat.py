@@ -319,3 +319,30 @@ def test_distinctive_descriptor_known_answer(oracle):
     # two rows: the median index is (int)(0.5*1) = 0, the distance of a row to itself: index 0 wins
     assert oracle.distinctive_descriptor(np.stack([d, a])) == 0
     assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == -1
+
+
+def test_search_by_bow_known_answer(oracle):
+    """ORBmatcher::SearchByBoW by hand.  Node 5 holds two frame features: f0 = X and f1 = X with bits
+    100..109 flipped, and two key-frame features: k0 = X with bit 0 flipped (distances 1 and 11: takes f0),
+    k1 = X with bits 1,2 flipped (f0 is taken, so only f1 at distance 12 remains: best 12, second 256).
+    Node 6 exists only in the key frame, node 9 only in the frame: both are skipped."""
+    def flip(row, bits):
+        b = np.unpackbits(row.copy())
+        b[list(bits)] ^= 1
+        return np.packbits(b)
+
+    x = np.random.default_rng(2).integers(0, 256, size=32, dtype=np.uint8)
+    d2 = np.stack([x, flip(x, range(100, 110)), flip(x, range(0, 256, 2))])
+    d1 = np.stack([flip(x, [0]), flip(x, [1, 2]), flip(x, [3])])
+    nodes1 = (np.array([5, 6], np.int32), np.array([0, 2, 3], np.int32), np.array([0, 1, 2], np.int32))
+    nodes2 = (np.array([5, 9], np.int32), np.array([0, 2, 3], np.int32), np.array([0, 1, 2], np.int32))
+    ang = np.zeros(3, np.float32)
+    n, m12, m21 = oracle.search_by_bow(d1, ang, None, nodes1, d2, ang, None, nodes2, False, 0.6, True)
+    assert n == 2 and list(m12) == [0, 1, -1] and list(m21) == [0, 1, -1]
+    # without a usable map point k0 is skipped and k1 takes f0 (distance 2 against 12: 2 < 0.6 * 12)
+    n, m12, m21 = oracle.search_by_bow(d1, ang, np.array([0, 1, 1], np.uint8), nodes1, d2, ang, None, nodes2, False,
+                                       0.6, True)
+    assert n == 1 and list(m12) == [-1, 0, -1]
+    # the ratio test: 0.1 * 11 is not above 1
+    n, m12, _ = oracle.search_by_bow(d1, ang, None, nodes1, d2, ang, None, nodes2, False, 0.05, True)
+    assert n == 0 and list(m12) == [-1, -1, -1]
