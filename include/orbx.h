@@ -112,6 +112,11 @@ int orbx_batch_counts(orbx_extractor *ex, int *n_per_frame, int *n_per_level);
 /* Downloads the keypoints and descriptors of one frame of the last batch. */
 int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint *keypoints, uint8_t *descriptors, int cap,
                         int *n_out);
+/* Downloads the whole last batch with one synchronisation: frame f's keypoints start at
+ * keypoints + f*cap_per_frame, its descriptors at descriptors + f*cap_per_frame*32, counts[f] of them
+ * are valid.  cap_per_frame >= orbx_extractor_max_keypoints. */
+int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *keypoints, uint8_t *descriptors, int cap_per_frame,
+                            int *counts);
 /* Device addresses of the result arrays of the last batch: keypoints (frame f at
  * +f*max_keypoints entries), descriptors (32 bytes each, same indexing), per-frame counts. */
 int orbx_batch_device_results(orbx_extractor *ex, const orbx_keypoint **d_keypoints, const uint8_t **d_descriptors,

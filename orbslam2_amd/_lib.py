@@ -58,6 +58,7 @@ SIGNATURES = {
     "orbx_extract_batch_host": (C.c_int, [_P, C.POINTER(_P), C.c_int, C.c_int, C.c_int, C.c_int]),
     "orbx_batch_counts": (C.c_int, [_P, _i32p, _i32p]),
     "orbx_batch_download": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _i32p]),
+    "orbx_batch_download_all": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "orbx_batch_device_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _i32p]),
     "orbx_stage_name": (C.c_char_p, [C.c_int]),
     "orbx_extractor_profile": (C.c_int, [_P, C.c_int]),

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "orbx_internal.h"
@@ -584,18 +585,36 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
     } else {
         HIP_TRY(hipEventSynchronize(ex->ev_staged));  // the previous batch has left the staging buffer
     }
-    HIP_TRY(prof_mark(ex, 0, 0, ex->stream));
-    for (int f = 0; f < batch; f++) {
+    for (int f = 0; f < batch; f++)
         if (!images[f])
             return ORBX_E_ARG;
+    HIP_TRY(prof_mark(ex, 0, 0, ex->stream));
+    // rows into the staging buffer: on the calling thread for a few frames, else on up to four threads,
+    // each followed by the asynchronous copies of its frames (in frame order on the one stream)
+    auto stage = [&](int f) {
         uint8_t *st = ex->h_stage + (size_t)f * frame_bytes;
         if (stride_bytes == L0.pitch)
             memcpy(st, images[f], frame_bytes);
         else
             for (int y = 0; y < height; y++)
                 memcpy(st + (size_t)y * L0.pitch, images[f] + (size_t)y * stride_bytes, width);
-        HIP_TRY(hipMemcpyAsync(ex->buf.pyr + (size_t)f * ex->geom.slab + L0.off, st, frame_bytes,
-                               hipMemcpyHostToDevice, ex->stream));
+    };
+    const int nthreads = batch >= 8 ? 4 : 1;
+    if (nthreads > 1) {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++)
+            pool.emplace_back([&, t]() {
+                for (int f = t; f < batch; f += nthreads)
+                    stage(f);
+            });
+        for (auto &th : pool)
+            th.join();
+    }
+    for (int f = 0; f < batch; f++) {
+        if (nthreads == 1)
+            stage(f);
+        HIP_TRY(hipMemcpyAsync(ex->buf.pyr + (size_t)f * ex->geom.slab + L0.off, ex->h_stage + (size_t)f * frame_bytes,
+                               frame_bytes, hipMemcpyHostToDevice, ex->stream));
     }
     HIP_TRY(hipEventRecord(ex->ev_staged, ex->stream));
     ex->buf.l0 = OrbxLevel0{ex->buf.pyr + L0.off, (long long)ex->geom.slab, L0.pitch};
@@ -684,6 +703,32 @@ extern "C" int orbx_batch_download(orbx_extractor *ex, int frame, orbx_keypoint 
                                    ex->stream));
         HIP_TRY(hipStreamSynchronize(ex->stream));
     }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *keypoints, uint8_t *descriptors,
+                                       int cap_per_frame, int *counts)
+{
+    if (!ex || !keypoints || !descriptors || !counts)
+        return ORBX_E_ARG;
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    const int B = ex->geom.batch, oc = ex->geom.out_cap;
+    if (cap_per_frame < oc)
+        return ORBX_E_CAPACITY;
+    HIP_TRY(hipSetDevice(ex->device));
+    int status[ORBX_ST_COUNT];
+    HIP_TRY(hipMemcpyAsync(counts, ex->buf.out_n, sizeof(int) * B, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(status, ex->buf.status, sizeof(status), hipMemcpyDeviceToHost, ex->stream));
+    // frame f of the device arrays starts at f * out_cap entries; the caller's at f * cap_per_frame
+    HIP_TRY(hipMemcpy2DAsync(keypoints, (size_t)cap_per_frame * sizeof(orbx_keypoint), ex->buf.out_kp,
+                             (size_t)oc * sizeof(orbx_keypoint), (size_t)oc * sizeof(orbx_keypoint), B,
+                             hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpy2DAsync(descriptors, (size_t)cap_per_frame * 32, ex->buf.out_desc, (size_t)oc * 32,
+                             (size_t)oc * 32, B, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    if (status[ORBX_ST_CAND_OVERFLOW] || status[ORBX_ST_NODE_OVERFLOW])
+        return ORBX_E_CAPACITY;
     return ORBX_OK;
 }
 

@@ -136,6 +136,17 @@ class ORBextractor:
                 "orbx_batch_download")
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def batch_download_all(self):
+        """Keypoints and descriptors of every frame of the last batch with one synchronisation:
+        returns a list of (keypoints, descriptors) per frame."""
+        b, cap = self._last[0], self.max_keypoints
+        kps = np.zeros((b, cap), L.KEYPOINT_DTYPE)
+        desc = np.zeros((b, cap, 32), np.uint8)
+        n = np.zeros(b, np.int32)
+        L.check(self._lib.orbx_batch_download_all(self._h, L.ptr(kps), L.ptr(desc), cap, L.ptr(n)),
+                "orbx_batch_download_all")
+        return [(kps[f, :n[f]], desc[f, :n[f]]) for f in range(b)]
+
     def device_results(self):
         kp, de, cn = C.c_void_p(), C.c_void_p(), C.c_void_p()
         cap = C.c_int(0)

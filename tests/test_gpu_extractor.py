@@ -322,3 +322,17 @@ def test_large_image_and_wide_scale_steps(oracle):
             assert np.array_equal(e2.pyramid_level(0, l), tr["levels"][l]), (sc, l)
         compare_frame(kg, dg, ko, do)
         e2.close()
+
+
+def test_batch_download_all_equals_per_frame(oracle):
+    w, h, B = 640, 480, 9   # nine frames: the staging copy runs on several threads
+    imgs = [orbx.synth_image(SEED + 31 * i, w, h, 0 if i != 4 else 1) for i in range(B)]
+    ex = make_extractor(TUM, w, h, batch=B)
+    ex.extract_batch_host(imgs)
+    both = ex.batch_download_all()
+    for f in range(B):
+        k, d = ex.batch_download(f)
+        assert np.array_equal(both[f][0], k) and np.array_equal(both[f][1], d)
+    ko, do = oracle_extract(oracle, imgs[7], TUM)
+    compare_frame(both[7][0], both[7][1], ko, do)
+    assert len(both[4][0]) == 0

@@ -27,6 +27,12 @@ for _ in range(reps):
 dt = time.perf_counter() - t0
 print("host-to-host: %.0f frames/s (batch %d, per-frame download calls included)" % (reps * B / dt, B))
 t0 = time.perf_counter()
+for _ in range(reps):
+    ex.extract_batch_host(imgs)
+    out = ex.batch_download_all()
+dt = time.perf_counter() - t0
+print("host-to-host: %.0f frames/s (batch %d, one download call per batch)" % (reps * B / dt, B))
+t0 = time.perf_counter()
 for _ in range(reps * 4):
     ex(imgs[0])
 dt = time.perf_counter() - t0
