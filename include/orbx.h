@@ -249,6 +249,28 @@ int orbx_search_for_initialization_batch_device(orbx_matcher *m, const orbx_keyp
                                                 int check_orientation, int32_t *d_matches12, int32_t *d_nmatches,
                                                 int32_t *d_pair_counts);
 
+/* The 64x48 lookup grid of Frame (include/Frame.h:38-39).  orbx_frame_grid_build_device is
+ * Frame::AssignFeaturesToGrid with Frame::PosInGrid (src/Frame.cc:239-253, 409-420) for n <= 32768
+ * keypoints in device memory (bounds = mnMinX, mnMaxX, mnMinY, mnMaxY): d_cell_start receives 64*48+1
+ * offsets (cell = column*48 + row), d_cell_items the keypoint indices cell by cell, ascending inside a
+ * cell as the reference appends them; keypoints outside the grid are in no cell.
+ * orbx_features_in_area_device is Frame::GetFeaturesInArea (:349-407) for nq queries (x, y, r, minLevel,
+ * maxLevel) at once: query q's indices go to d_out_idx + q*cap in the reference's order (cell column,
+ * cell row, keypoint index), d_out_n[q] is their number (the list is truncated if it exceeds cap).
+ * Device pointers, asynchronous on the matcher's stream. */
+int orbx_frame_grid_build_device(orbx_matcher *m, const orbx_keypoint *d_keypoints, int n, float min_x, float max_x,
+                                 float min_y, float max_y, int32_t *d_cell_start, int32_t *d_cell_items);
+int orbx_features_in_area_device(orbx_matcher *m, const orbx_keypoint *d_keypoints, float min_x, float max_x,
+                                 float min_y, float max_y, const int32_t *d_cell_start, const int32_t *d_cell_items,
+                                 const float *d_x, const float *d_y, const float *d_r, const int32_t *d_min_level,
+                                 const int32_t *d_max_level, int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n);
+/* Both steps from host arrays (keypoints and queries in, lists out); cell_start / cell_items may be
+ * NULL when the grid itself is not wanted. */
+int orbx_features_in_area(orbx_matcher *m, const orbx_keypoint *keypoints, int n, float min_x, float max_x, float min_y,
+                          float max_y, const float *x, const float *y, const float *r, const int32_t *min_level,
+                          const int32_t *max_level, int nq, int cap, int32_t *out_idx, int32_t *out_n,
+                          int32_t *cell_start, int32_t *cell_items);
+
 /* ORBmatcher::SearchByBoW for nb key frames ("side 1") against one frame or key frame ("side 2"):
  * src/ORBmatcher.cc:176-311 (key frame against frame: strict_lt = 0, valid2 = NULL; this is what
  * Tracking::Relocalization runs for every candidate key frame, src/Tracking.cc:1573-1586) and :552-686

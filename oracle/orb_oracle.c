@@ -986,6 +986,28 @@ int orc_features_in_area(const orc_grid *g, const orc_keypoint *kps, float x, fl
     return n;
 }
 
+/* Flat form of the two functions above for callers without the struct: builds the grid of n keypoints,
+ * copies its CSR arrays out (cell_start: 64*48+1 entries, cell_items: up to n) and answers nq queries;
+ * out_idx holds cap entries per query, out_n the (untruncated) counts. */
+void orc_grid_queries(const orc_keypoint *kps, int n, float min_x, float max_x, float min_y, float max_y,
+                      const float *x, const float *y, const float *r, const int *min_level, const int *max_level,
+                      int nq, int cap, int *out_idx, int *out_n, int *cell_start, int *cell_items)
+{
+    orc_grid g;
+    orc_grid_build(&g, kps, n, min_x, max_x, min_y, max_y);
+    const int ncell = ORC_GRID_COLS * ORC_GRID_ROWS;
+    memcpy(cell_start, g.cell_start, sizeof(int) * (size_t)(ncell + 1));
+    memcpy(cell_items, g.cell_items, sizeof(int) * (size_t)g.cell_start[ncell]);
+    int *tmp = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int q = 0; q < nq; q++) {
+        const int c = orc_features_in_area(&g, kps, x[q], y[q], r[q], min_level[q], max_level[q], tmp);
+        out_n[q] = c;
+        memcpy(out_idx + (size_t)q * cap, tmp, sizeof(int) * (size_t)(c < cap ? c : cap));
+    }
+    free(tmp);
+    orc_grid_free(&g);
+}
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1698-1739 */
 void orc_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3)
 {

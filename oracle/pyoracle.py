@@ -305,3 +305,23 @@ def search_by_bow(d1, ang1, valid1, nodes1, d2, ang2, valid2, nodes2, strict_lt,
            _p(ang2), None if v2 is None else _p(v2), len(d2), _p(i2), _p(s2), _p(t2), len(i2), int(strict_lt), ratio,
            int(check_ori), _p(m12), _p(m21))
     return n, m12, m21
+
+
+def grid_queries(kps, bounds, x, y, r, min_level, max_level, cap=512):
+    """Frame::AssignFeaturesToGrid + GetFeaturesInArea: (list of index arrays, cell_start, cell_items)."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (x, y, r))
+    lo, hi = (np.ascontiguousarray(a, np.int32) for a in (min_level, max_level))
+    nq = len(qx)
+    out = np.zeros((max(nq, 1), cap), np.int32)
+    cnt = np.zeros(max(nq, 1), np.int32)
+    cs = np.zeros(64 * 48 + 1, np.int32)
+    ci = np.zeros(max(len(kps), 1), np.int32)
+    fn = lib().orc_grid_queries
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn(_p(kps), len(kps), bounds[0], bounds[1], bounds[2], bounds[3], _p(qx), _p(qy), _p(qr), _p(lo), _p(hi), nq, cap,
+       _p(out), _p(cnt), _p(cs), _p(ci))
+    assert nq == 0 or cnt[:nq].max() <= cap
+    return [out[q, :cnt[q]].copy() for q in range(nq)], cs, ci[:cs[-1]].copy()

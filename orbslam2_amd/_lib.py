@@ -85,6 +85,11 @@ SIGNATURES = {
     "orbx_compute_stereo_matches_device": (C.c_int, [_P, _P, C.c_float, C.c_float, _P, _P, _P]),
     "orbx_compute_stereo_matches": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, _P, _P, C.c_int,
                                               C.POINTER(C.c_int)]),
+    "orbx_frame_grid_build_device": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "orbx_features_in_area_device": (C.c_int, [_P, _P, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P, _P,
+                                               _P, _P, C.c_int, C.c_int, _P, _P]),
+    "orbx_features_in_area": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P,
+                                        _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "orbx_search_by_bow": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P,
                                      C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P]),
     "orbx_distinctive_descriptors_device": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),

@@ -1452,6 +1452,92 @@ extern "C" int orbx_search_for_initialization_batch_device(orbx_matcher *m, cons
     return ORBX_OK;
 }
 
+extern "C" int orbx_frame_grid_build_device(orbx_matcher *m, const orbx_keypoint *d_keypoints, int n, float min_x,
+                                            float max_x, float min_y, float max_y, int32_t *d_cell_start,
+                                            int32_t *d_cell_items)
+{
+    if (!m || n < 0 || n > 32768 || (n > 0 && (!d_keypoints || !d_cell_items)) || !d_cell_start || !(max_x > min_x) ||
+        !(max_y > min_y))
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = grow(&m->d_seg, &m->seg_cap, (size_t)std::max(n, 1), m->stream);  // sort keys
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(orbx_launch_grid_build(d_keypoints, n, min_x, max_x, min_y, max_y, (uint32_t *)m->d_seg, d_cell_start,
+                                   d_cell_items, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_features_in_area_device(orbx_matcher *m, const orbx_keypoint *d_keypoints, float min_x, float max_x,
+                                            float min_y, float max_y, const int32_t *d_cell_start,
+                                            const int32_t *d_cell_items, const float *d_x, const float *d_y,
+                                            const float *d_r, const int32_t *d_min_level, const int32_t *d_max_level,
+                                            int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n)
+{
+    if (!m || nq < 0 || cap < 0 || !d_cell_start || !(max_x > min_x) || !(max_y > min_y) ||
+        (nq > 0 && (!d_x || !d_y || !d_r || !d_min_level || !d_max_level || !d_out_n || (cap > 0 && !d_out_idx))))
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(orbx_launch_features_in_area(d_keypoints, min_x, max_x, min_y, max_y, d_cell_start, d_cell_items, d_x, d_y,
+                                         d_r, d_min_level, d_max_level, nq, cap, d_out_idx, d_out_n, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_features_in_area(orbx_matcher *m, const orbx_keypoint *keypoints, int n, float min_x, float max_x,
+                                     float min_y, float max_y, const float *x, const float *y, const float *r,
+                                     const int32_t *min_level, const int32_t *max_level, int nq, int cap,
+                                     int32_t *out_idx, int32_t *out_n, int32_t *cell_start, int32_t *cell_items)
+{
+    if (!m || n < 0 || n > 32768 || nq < 0 || cap < 0 || (n > 0 && !keypoints) ||
+        (nq > 0 && (!x || !y || !r || !min_level || !max_level || !out_n || (cap > 0 && !out_idx))))
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += (std::max<size_t>(bytes, 4) + 255) / 256 * 256;
+        return at;
+    };
+    const size_t o_kp = carve((size_t)n * sizeof(orbx_keypoint)), o_cs = carve((size_t)(64 * 48 + 1) * 4);
+    const size_t o_ci = carve((size_t)n * 4), o_x = carve((size_t)nq * 4), o_y = carve((size_t)nq * 4);
+    const size_t o_r = carve((size_t)nq * 4), o_lo = carve((size_t)nq * 4), o_hi = carve((size_t)nq * 4);
+    const size_t o_out = carve((size_t)nq * cap * 4), o_n = carve((size_t)nq * 4);
+    int rc = grow(&m->d_ws, &m->ws_cap, off, m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    uint8_t *w = m->d_ws;
+    auto up = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(w + at, src, bytes, hipMemcpyHostToDevice, m->stream) : hipSuccess;
+    };
+    HIP_TRY(up(o_kp, keypoints, (size_t)n * sizeof(orbx_keypoint)));
+    HIP_TRY(up(o_x, x, (size_t)nq * 4));
+    HIP_TRY(up(o_y, y, (size_t)nq * 4));
+    HIP_TRY(up(o_r, r, (size_t)nq * 4));
+    HIP_TRY(up(o_lo, min_level, (size_t)nq * 4));
+    HIP_TRY(up(o_hi, max_level, (size_t)nq * 4));
+    rc = orbx_frame_grid_build_device(m, (const orbx_keypoint *)(w + o_kp), n, min_x, max_x, min_y, max_y,
+                                      (int32_t *)(w + o_cs), (int32_t *)(w + o_ci));
+    if (rc != ORBX_OK)
+        return rc;
+    rc = orbx_features_in_area_device(m, (const orbx_keypoint *)(w + o_kp), min_x, max_x, min_y, max_y,
+                                      (const int32_t *)(w + o_cs), (const int32_t *)(w + o_ci), (const float *)(w + o_x),
+                                      (const float *)(w + o_y), (const float *)(w + o_r), (const int32_t *)(w + o_lo),
+                                      (const int32_t *)(w + o_hi), nq, cap, (int32_t *)(w + o_out), (int32_t *)(w + o_n));
+    if (rc != ORBX_OK)
+        return rc;
+    if (nq > 0) {
+        if (cap > 0)
+            HIP_TRY(hipMemcpyAsync(out_idx, w + o_out, (size_t)nq * cap * 4, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(out_n, w + o_n, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    if (cell_start)
+        HIP_TRY(hipMemcpyAsync(cell_start, w + o_cs, (size_t)(64 * 48 + 1) * 4, hipMemcpyDeviceToHost, m->stream));
+    if (cell_items && n > 0)
+        HIP_TRY(hipMemcpyAsync(cell_items, w + o_ci, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1,
                                   const int32_t *feat_start, int nb, const int32_t *node_kf_start,
                                   const int32_t *node_ids1, const int32_t *node_start1, const int32_t *node_items1,

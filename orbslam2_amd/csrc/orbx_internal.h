@@ -141,6 +141,12 @@ hipError_t orbx_launch_bow(const uint8_t *d_desc1, const float *d_ang1, const ui
                            const uint8_t *d_valid2, int n2, const int *d_ids2, const int *d_start2, const int *d_items2,
                            int m2, int strict_lt, float ratio, int check_ori, int *d_match12, int *d_match21,
                            int *d_nmatches, int8_t *d_bin_of, int *d_hist, int *d_status, hipStream_t s);
+hipError_t orbx_launch_grid_build(const orbx_keypoint *d_kp, int n, float min_x, float max_x, float min_y, float max_y,
+                                  uint32_t *d_keys, int32_t *d_cell_start, int32_t *d_cell_items, hipStream_t s);
+hipError_t orbx_launch_features_in_area(const orbx_keypoint *d_kp, float min_x, float max_x, float min_y, float max_y,
+                                        const int32_t *d_cell_start, const int32_t *d_cell_items, const float *d_qx,
+                                        const float *d_qy, const float *d_qr, const int *d_qmin, const int *d_qmax,
+                                        int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n, hipStream_t s);
 size_t orbx_search_init_lds_bytes(int cap0);
 hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_desc, const int *d_counts, int max_kp,
                                    int npairs, int cap0, float min_x, float max_x, float min_y, float max_y,

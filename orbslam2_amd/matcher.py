@@ -186,3 +186,24 @@ class ORBmatcher:
                 "orbx_search_by_bow")
         per_kf = [m12[feat_start[b]:feat_start[b + 1]].copy() for b in range(nb)]
         return nm[:nb].copy(), per_kf, m21[:nb, :n2].copy()
+
+    def GetFeaturesInArea(self, keypoints, bounds, x, y, r, min_level, max_level, cap=512):
+        """Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (src/Frame.cc:239-253, 349-420) for a batch of
+        queries: keypoints = KEYPOINT_DTYPE array (mvKeysUn), bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY),
+        x/y/r/min_level/max_level = arrays of equal length.  Returns (list of index arrays, cell_start,
+        cell_items)."""
+        kps = np.ascontiguousarray(keypoints, L.KEYPOINT_DTYPE)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (x, y, r))
+        lo, hi = (np.ascontiguousarray(a, np.int32) for a in (min_level, max_level))
+        nq = len(qx)
+        out = np.zeros((max(nq, 1), cap), np.int32)
+        cnt = np.zeros(max(nq, 1), np.int32)
+        cs = np.zeros(64 * 48 + 1, np.int32)
+        ci = np.zeros(max(len(kps), 1), np.int32)
+        L.check(self._lib.orbx_features_in_area(self._handle(), L.ptr(kps), len(kps), bounds[0], bounds[1], bounds[2],
+                                                bounds[3], L.ptr(qx), L.ptr(qy), L.ptr(qr), L.ptr(lo), L.ptr(hi), nq,
+                                                cap, L.ptr(out), L.ptr(cnt), L.ptr(cs), L.ptr(ci)),
+                "orbx_features_in_area")
+        if nq and cnt[:nq].max() > cap:
+            raise L.OrbxError(-3, "GetFeaturesInArea: a list exceeds cap=%d" % cap)
+        return [out[q, :cnt[q]].copy() for q in range(nq)], cs, ci[:cs[-1]].copy()

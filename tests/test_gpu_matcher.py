@@ -291,3 +291,35 @@ def test_search_by_bow_vs_oracle(oracle, strict, ratio, ori):
                  node_ids=np.zeros(0, np.int32), node_start=np.zeros(1, np.int32), node_items=np.zeros(0, np.int32))
     nm, m12, m21 = m.SearchByBoW([empty], frame)
     assert nm[0] == 0 and (m21 == -1).all()
+
+
+def test_frame_grid_and_area_queries_vs_oracle(oracle):
+    """AssignFeaturesToGrid / GetFeaturesInArea: the CSR grid and the ordered result lists of a batch of
+    queries (windows of several sizes, level filters, centres outside the image, keypoints outside the
+    grid bounds) must equal the oracle's."""
+    rng = np.random.default_rng(13)
+    n = 3000
+    kps = np.zeros(n, orbx.KEYPOINT_DTYPE)
+    kps["x"] = rng.random(n).astype(np.float32) * 1300 - 30     # some outside [0, 1241)
+    kps["y"] = rng.random(n).astype(np.float32) * 400 - 12
+    kps["x"][:200] = np.round(kps["x"][:200])                   # exact cell borders and repeated positions
+    kps["y"][:200] = np.round(kps["y"][:200] / 7.8333) * 7.8333
+    kps["octave"] = rng.integers(0, 8, size=n)
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    nq = 500
+    qx = (rng.random(nq) * 1400 - 80).astype(np.float32)
+    qy = (rng.random(nq) * 450 - 40).astype(np.float32)
+    qr = rng.choice([5.0, 10.0, 15.0, 40.0, 100.0, 700.0], size=nq).astype(np.float32)
+    lo = rng.choice([-1, 0, 0, 2, 5], size=nq).astype(np.int32)
+    hi = np.where(rng.random(nq) < 0.3, -1, lo + rng.integers(0, 3, size=nq)).astype(np.int32)
+    m = orbx.ORBmatcher()
+    got, cs, ci = m.GetFeaturesInArea(kps, bounds, qx, qy, qr, lo, hi, cap=3000)
+    want, ocs, oci = oracle.grid_queries(kps, bounds, qx, qy, qr, lo, hi, cap=3000)
+    assert np.array_equal(cs, ocs) and np.array_equal(ci, oci)
+    assert cs[-1] < n            # keypoints outside the grid were dropped
+    for q in range(nq):
+        assert np.array_equal(got[q], want[q]), q
+    assert max(len(g) for g in got) > 1000 and min(len(g) for g in got) == 0
+    # no keypoints at all
+    got, cs, _ = m.GetFeaturesInArea(kps[:0], bounds, qx[:3], qy[:3], qr[:3], lo[:3], hi[:3])
+    assert cs[-1] == 0 and all(len(g) == 0 for g in got)
