@@ -293,6 +293,29 @@ int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const float *angle
                        const int32_t *node_start2, const int32_t *node_items2, int m2, int strict_lt, float nnratio,
                        int check_orientation, int32_t *match12, int32_t *match21, int32_t *nmatches);
 
+/* ---------------------------------------------------------------- vocabulary */
+
+/* The descriptor -> word quantisation of DBoW2: TemplatedVocabulary<FORB::TDescriptor, FORB>::transform
+ * for single features (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259; FORB::distance,
+ * Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101), which Frame::ComputeBoW / KeyFrame::ComputeBoW run for every
+ * descriptor (src/Frame.cc:422-431 with levelsup = 4).  The tree is handed over flat, as the loaders
+ * of the reference build it (:1350-1420): node 0 is the root, node_desc holds 32 bytes per node, the
+ * children of node i are children[child_start[i] .. child_start[i+1]) in the stored order (every child id
+ * is larger than its parent's), word_id and weight are read at leaves, depth = L of the vocabulary.
+ * transform: per feature the word id, its weight and the id of the node passed at level
+ * depth - levelsup (0 when that level is <= 0); the first child wins distance ties.  The caller folds
+ * these into BowVector / FeatureVector (TemplatedVocabulary.h:1145-1193), which is map bookkeeping. */
+typedef struct orbx_vocabulary orbx_vocabulary;
+int orbx_vocabulary_create(int device, const uint8_t *node_desc, const int32_t *child_start, const int32_t *children,
+                           const int32_t *word_id, const double *weight, int nnodes, int depth,
+                           orbx_vocabulary **out);
+void orbx_vocabulary_destroy(orbx_vocabulary *v);
+/* device pointers in and out; asynchronous on `hip_stream` (NULL = the default stream) */
+int orbx_vocabulary_transform_device(orbx_vocabulary *v, void *hip_stream, const uint8_t *d_descriptors, int n,
+                                     int levelsup, int32_t *d_word, int32_t *d_node, double *d_weight);
+int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup, int32_t *word,
+                              int32_t *node, double *weight);
+
 /* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:248-319) for npoints map points at once.
  * The descriptors observed for point p are rows seg_start[p] .. seg_start[p+1]-1 of `descriptors`
  * (32 bytes each, in the order the caller collected them; the reference walks a

@@ -1398,6 +1398,45 @@ int orc_search_by_bow(const uint8_t *d1, const float *ang1, const uint8_t *valid
     return nmatches;
 }
 
+/* ------------------------------------------------------------------ vocabulary transform */
+
+/* TemplatedVocabulary<FORB>::transform for single features (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:
+ * 1217-1259, distance = FORB::distance, Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101, a popcount of a XOR): a
+ * feature descends from the root, at every node to the child with the smallest distance (the first child
+ * wins ties), until a leaf.  The tree is given flat: node_desc (32 bytes per node), the children of node i
+ * are children[child_start[i] .. child_start[i+1]), word_id (leaf) and weight per node; L = depth of the
+ * tree.  Outputs per feature: word id, weight and the id of the node reached at level L - levelsup
+ * (0 = root when that level is <= 0). */
+void orc_vocabulary_transform(const uint8_t *node_desc, const int *child_start, const int *children,
+                              const int *word_id, const double *weight, int L, const uint8_t *feat, int n,
+                              int levelsup, int *out_word, int *out_node, double *out_weight)
+{
+    const int nid_level = L - levelsup;
+    for (int f = 0; f < n; f++) {
+        int nid = 0, final_id = 0, level = 0;
+        do {
+            ++level;
+            const int c0 = child_start[final_id], c1 = child_start[final_id + 1];
+            int best_id = children[c0];
+            int best_d = orc_popcnt256(feat + (size_t)f * 32, node_desc + (size_t)best_id * 32);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = children[c];
+                const int d = orc_popcnt256(feat + (size_t)f * 32, node_desc + (size_t)id * 32);
+                if (d < best_d) {
+                    best_d = d;
+                    best_id = id;
+                }
+            }
+            final_id = best_id;
+            if (level == nid_level)
+                nid = final_id;
+        } while (child_start[final_id] != child_start[final_id + 1]);
+        out_word[f] = word_id[final_id];
+        out_node[f] = nid;
+        out_weight[f] = weight[final_id];
+    }
+}
+
 /* ------------------------------------------------------------------ distinctive descriptor */
 
 static int orc_cmp_int(const void *a, const void *b)

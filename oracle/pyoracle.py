@@ -325,3 +325,22 @@ def grid_queries(kps, bounds, x, y, r, min_level, max_level, cap=512):
        _p(out), _p(cnt), _p(cs), _p(ci))
     assert nq == 0 or cnt[:nq].max() <= cap
     return [out[q, :cnt[q]].copy() for q in range(nq)], cs, ci[:cs[-1]].copy()
+
+
+def vocabulary_transform(tree, feat, levelsup):
+    """tree = dict(desc (N,32) uint8, child_start (N+1,) int32, children int32, word_id (N,) int32,
+    weight (N,) float64, L).  Returns (word, node, weight) per feature."""
+    feat = np.ascontiguousarray(feat, np.uint8).reshape(-1, 32)
+    n = len(feat)
+    word = np.zeros(max(n, 1), np.int32)
+    node = np.zeros(max(n, 1), np.int32)
+    wt = np.zeros(max(n, 1), np.float64)
+    fn = lib().orc_vocabulary_transform
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p]
+    arrs = [np.ascontiguousarray(tree["desc"], np.uint8), np.ascontiguousarray(tree["child_start"], np.int32),
+            np.ascontiguousarray(tree["children"], np.int32), np.ascontiguousarray(tree["word_id"], np.int32),
+            np.ascontiguousarray(tree["weight"], np.float64)]
+    fn(*[_p(a) for a in arrs], tree["L"], _p(feat), n, levelsup, _p(word), _p(node), _p(wt))
+    return word[:n], node[:n], wt[:n]

@@ -92,6 +92,10 @@ SIGNATURES = {
                                         _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "orbx_search_by_bow": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P,
                                      C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P]),
+    "orbx_vocabulary_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "orbx_vocabulary_destroy": (None, [_P]),
+    "orbx_vocabulary_transform_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "orbx_vocabulary_transform": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "orbx_distinctive_descriptors_device": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     "orbx_distinctive_descriptors": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     "orbx_synth_image": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, _P, C.c_int]),

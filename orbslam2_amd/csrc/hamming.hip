@@ -245,3 +245,67 @@ hipError_t orbx_launch_distinctive(const uint8_t *d_desc, const int *d_seg_start
                                          reinterpret_cast<uint32_t *>(d_best_desc));
     return hipGetLastError();
 }
+
+// ---- TemplatedVocabulary<FORB>::transform of single features ----
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1217-1259 of the reference; FORB::distance,
+// Thirdparty/DBoW2/DBoW2/FORB.cpp:81-101, is a popcount of a XOR.)  One thread per feature descends the
+// flat tree: at every node to the child with the smallest distance, the first child on ties, until a
+// leaf; the node passed at level depth - levelsup is the feature-vector node.  The distances of one
+// node's children are independent loads; the levels are a dependent chain (depth of the tree).
+__global__ __launch_bounds__(256) void k_voc_transform(const uint32_t *__restrict__ node_desc,
+                                                       const int *__restrict__ child_start,
+                                                       const int *__restrict__ children,
+                                                       const int *__restrict__ word_id,
+                                                       const double *__restrict__ weight, int depth,
+                                                       const uint32_t *__restrict__ feat, int n, int levelsup,
+                                                       int *__restrict__ out_word, int *__restrict__ out_node,
+                                                       double *__restrict__ out_weight)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n)
+        return;
+    uint32_t a[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+        a[w] = feat[(size_t)f * 8 + w];
+    const int nid_level = depth - levelsup;
+    int nid = 0, final_id = 0, level = 0;
+    int c0 = child_start[0], c1 = child_start[1];
+    do {  // the host checked that children have larger ids than their parent: the descent ends
+        ++level;
+        int best_id = children[c0];
+        uint32_t best_d = 0xffffffffu;
+        for (int c = c0; c < c1; c++) {
+            const int id = children[c];
+            const uint32_t *r = node_desc + (size_t)id * 8;
+            uint32_t d = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++)
+                d += __popc(a[w] ^ r[w]);
+            if (d < best_d) {
+                best_d = d;
+                best_id = id;
+            }
+        }
+        final_id = best_id;
+        if (level == nid_level)
+            nid = final_id;
+        c0 = child_start[final_id], c1 = child_start[final_id + 1];
+    } while (c0 != c1);
+    out_word[f] = word_id[final_id];
+    out_node[f] = nid;
+    out_weight[f] = weight[final_id];
+}
+
+hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_child_start, const int *d_children,
+                                     const int *d_word_id, const double *d_weight, int depth, const uint8_t *d_feat,
+                                     int n, int levelsup, int *d_word, int *d_node, double *d_wt, hipStream_t s)
+{
+    if (n <= 0)
+        return hipSuccess;
+    k_voc_transform<<<(n + 255) / 256, 256, 0, s>>>(reinterpret_cast<const uint32_t *>(d_node_desc), d_child_start,
+                                                    d_children, d_word_id, d_weight, depth,
+                                                    reinterpret_cast<const uint32_t *>(d_feat), n, levelsup, d_word,
+                                                    d_node, d_wt);
+    return hipGetLastError();
+}

@@ -1656,6 +1656,118 @@ extern "C" int orbx_distinctive_descriptors(orbx_matcher *m, const uint8_t *desc
     return ORBX_OK;
 }
 
+// ------------------------------------------------------------------ vocabulary
+
+struct orbx_vocabulary {
+    int device, nnodes, depth;
+    uint8_t *d_desc;
+    int *d_child_start, *d_children, *d_word;
+    double *d_weight;
+    // feature and result arrays of the host form, grown on demand
+    uint8_t *d_ws;
+    size_t ws_cap;
+};
+
+extern "C" void orbx_vocabulary_destroy(orbx_vocabulary *v)
+{
+    if (!v)
+        return;
+    (void)hipSetDevice(v->device);
+    void *ptrs[] = {v->d_desc, v->d_child_start, v->d_children, v->d_word, v->d_weight, v->d_ws};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    delete v;
+}
+
+extern "C" int orbx_vocabulary_create(int device, const uint8_t *node_desc, const int32_t *child_start,
+                                      const int32_t *children, const int32_t *word_id, const double *weight, int nnodes,
+                                      int depth, orbx_vocabulary **out)
+{
+    if (!out || !node_desc || !child_start || !children || !word_id || !weight || nnodes < 2 || depth < 1)
+        return ORBX_E_ARG;
+    *out = nullptr;
+    // the root must have children, offsets must ascend, and a child must come after its parent (this
+    // also bounds every descent)
+    if (child_start[0] != 0 || child_start[1] <= 0)
+        return ORBX_E_ARG;
+    for (int i = 0; i < nnodes; i++) {
+        if (child_start[i + 1] < child_start[i])
+            return ORBX_E_ARG;
+        for (int c = child_start[i]; c < child_start[i + 1]; c++)
+            if (children[c] <= i || children[c] >= nnodes)
+                return ORBX_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+        return ORBX_E_NODEVICE;
+    orbx_vocabulary *v = new (std::nothrow) orbx_vocabulary();
+    if (!v)
+        return ORBX_E_CAPACITY;
+    memset(v, 0, sizeof(*v));
+    v->device = device, v->nnodes = nnodes, v->depth = depth;
+    const size_t nc = (size_t)child_start[nnodes];
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_desc, (size_t)nnodes * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_child_start, ((size_t)nnodes + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_children, std::max<size_t>(nc, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_word, (size_t)nnodes * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&v->d_weight, (size_t)nnodes * 8);
+    if (e == hipSuccess) e = hipMemcpy(v->d_desc, node_desc, (size_t)nnodes * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_start, child_start, ((size_t)nnodes + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_children, children, nc * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_word, word_id, (size_t)nnodes * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_weight, weight, (size_t)nnodes * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        g_last_hip = (int)e;
+        orbx_vocabulary_destroy(v);
+        return ORBX_E_HIP;
+    }
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" int orbx_vocabulary_transform_device(orbx_vocabulary *v, void *hip_stream, const uint8_t *d_descriptors,
+                                                int n, int levelsup, int32_t *d_word, int32_t *d_node,
+                                                double *d_weight)
+{
+    if (!v || n < 0 || levelsup < 0 || (n > 0 && (!d_descriptors || !d_word || !d_node || !d_weight)))
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(v->device));
+    HIP_TRY(orbx_launch_voc_transform(v->d_desc, v->d_child_start, v->d_children, v->d_word, v->d_weight, v->depth,
+                                      d_descriptors, n, levelsup, d_word, d_node, d_weight, (hipStream_t)hip_stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_vocabulary_transform(orbx_vocabulary *v, const uint8_t *descriptors, int n, int levelsup,
+                                         int32_t *word, int32_t *node, double *weight)
+{
+    if (!v || n < 0 || levelsup < 0 || (n > 0 && (!descriptors || !word || !node || !weight)))
+        return ORBX_E_ARG;
+    if (n == 0)
+        return ORBX_OK;
+    HIP_TRY(hipSetDevice(v->device));
+    const size_t o_f = 0, o_w = ((size_t)n * 32 + 255) / 256 * 256, o_n = o_w + ((size_t)n * 4 + 255) / 256 * 256;
+    const size_t o_wt = o_n + ((size_t)n * 4 + 255) / 256 * 256, total = o_wt + (size_t)n * 8;
+    if (total > v->ws_cap) {
+        if (v->d_ws)
+            HIP_TRY(hipFree(v->d_ws));
+        v->d_ws = nullptr, v->ws_cap = 0;
+        HIP_TRY(hipMalloc((void **)&v->d_ws, total + total / 4));
+        v->ws_cap = total + total / 4;
+    }
+    uint8_t *w = v->d_ws;
+    HIP_TRY(hipMemcpy(w + o_f, descriptors, (size_t)n * 32, hipMemcpyHostToDevice));
+    int rc = orbx_vocabulary_transform_device(v, nullptr, w + o_f, n, levelsup, (int32_t *)(w + o_w), (int32_t *)(w + o_n),
+                                              (double *)(w + o_wt));
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(hipMemcpy(word, w + o_w, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(node, w + o_n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(weight, w + o_wt, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
 // ------------------------------------------------------------------ synthetic inputs
 
 static inline uint64_t splitmix64(uint64_t &s)

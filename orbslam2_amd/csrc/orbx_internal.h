@@ -147,6 +147,9 @@ hipError_t orbx_launch_features_in_area(const orbx_keypoint *d_kp, float min_x, 
                                         const int32_t *d_cell_start, const int32_t *d_cell_items, const float *d_qx,
                                         const float *d_qy, const float *d_qr, const int *d_qmin, const int *d_qmax,
                                         int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n, hipStream_t s);
+hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_child_start, const int *d_children,
+                                     const int *d_word_id, const double *d_weight, int depth, const uint8_t *d_feat,
+                                     int n, int levelsup, int *d_word, int *d_node, double *d_wt, hipStream_t s);
 size_t orbx_search_init_lds_bytes(int cap0);
 hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_desc, const int *d_counts, int max_kp,
                                    int npairs, int cap0, float min_x, float max_x, float min_y, float max_y,

@@ -323,3 +323,60 @@ def test_frame_grid_and_area_queries_vs_oracle(oracle):
     # no keypoints at all
     got, cs, _ = m.GetFeaturesInArea(kps[:0], bounds, qx[:3], qy[:3], qr[:3], lo[:3], hi[:3])
     assert cs[-1] == 0 and all(len(g) == 0 for g in got)
+
+
+def _random_tree(rng, k, depth, early_leaf=0.1):
+    """A vocabulary tree in flat form with up to k children per node, leaves at depth `depth` and a few earlier."""
+    desc = [np.zeros(32, np.uint8)]
+    kids = [[]]
+    level = [0]
+    frontier = [0]
+    for lv in range(1, depth + 1):
+        nxt = []
+        for p in frontier:
+            if lv > 1 and rng.random() < early_leaf:
+                continue
+            for _ in range(int(rng.integers(2, k + 1))):
+                nid = len(desc)
+                base = desc[p] if lv > 1 and rng.random() < 0.5 else rng.integers(0, 256, size=32, dtype=np.uint8)
+                row = base.copy()
+                row[rng.integers(0, 32)] ^= np.uint8(rng.integers(1, 256))  # siblings close to each other: ties
+                desc.append(row)
+                kids.append([])
+                level.append(lv)
+                kids[p].append(nid)
+                nxt.append(nid)
+        frontier = nxt
+    n = len(desc)
+    child_start = np.zeros(n + 1, np.int32)
+    child_start[1:] = np.cumsum([len(c) for c in kids])
+    children = np.array([c for cs in kids for c in cs], np.int32)
+    word_id = np.full(n, -1, np.int32)
+    leaves = [i for i in range(n) if not kids[i]]
+    word_id[leaves] = np.arange(len(leaves))
+    weight = np.where(word_id >= 0, rng.random(n) * 5, 0.0)
+    weight[leaves[::17]] = 0.0          # stopped words
+    return dict(desc=np.stack(desc), child_start=child_start, children=children, word_id=word_id, weight=weight,
+                L=depth)
+
+
+def test_vocabulary_transform_vs_oracle(oracle):
+    rng = np.random.default_rng(33)
+    tree = _random_tree(rng, 10, 4)
+    voc = orbx.ORBVocabulary(tree["desc"], tree["child_start"], tree["children"], tree["word_id"], tree["weight"],
+                             tree["L"])
+    feats = rng.integers(0, 256, size=(3000, 32), dtype=np.uint8)
+    feats[:500] = tree["desc"][rng.integers(1, len(tree["desc"]), size=500)]      # exact node descriptors
+    for levelsup in (0, 1, 2, 4, 7):
+        w, nd, wt = voc.transform_features(feats, levelsup)
+        ow, ond, owt = oracle.vocabulary_transform(tree, feats, levelsup)
+        assert np.array_equal(w, ow) and np.array_equal(nd, ond) and np.array_equal(wt, owt), levelsup
+    assert (nd == 0).all()          # levelsup beyond the depth: the root
+    bow, fv = voc.transform(feats, 2)
+    assert abs(sum(bow.values()) - 1.0) < 1e-9 and sum(len(v) for v in fv.values()) == int((owt > 0).sum())
+    # malformed trees are refused: a child that precedes its parent
+    bad = dict(tree)
+    bad["children"] = tree["children"].copy()
+    bad["children"][-1] = 0
+    with pytest.raises(orbx.OrbxError):
+        orbx.ORBVocabulary(bad["desc"], bad["child_start"], bad["children"], bad["word_id"], bad["weight"], 4)

@@ -346,3 +346,25 @@ def test_search_by_bow_known_answer(oracle):
     # the ratio test: 0.1 * 11 is not above 1
     n, m12, _ = oracle.search_by_bow(d1, ang, None, nodes1, d2, ang, None, nodes2, False, 0.05, True)
     assert n == 0 and list(m12) == [-1, -1, -1]
+
+
+def test_vocabulary_transform_known_answer(oracle):
+    """A two-level tree by hand: root -> A (all zero), B (all ones); A -> A1 (zero), A2 (one bit set);
+    B is a leaf.  A feature with 3 bits set goes to A (3 < 253), then to A2 (2 < 3); the all-ones feature
+    goes to the leaf B; a feature at equal distance from A and B (128 bits set, bit 0 among them) takes the
+    first child A and there A2 (127 < 128)."""
+    z, o = np.zeros(32, np.uint8), np.full(32, 0xFF, np.uint8)
+    a2 = z.copy()
+    a2[0] = 0x01
+    desc = np.stack([z, z, o, z, a2])                  # 0 root, 1 A, 2 B, 3 A1, 4 A2
+    tree = dict(desc=desc, child_start=np.array([0, 2, 4, 4, 4, 4], np.int32), children=np.array([1, 2, 3, 4], np.int32),
+                word_id=np.array([-1, -1, 0, 1, 2], np.int32), weight=np.array([0, 0, 1.5, 2.5, 3.5]), L=2)
+    f1 = z.copy()
+    f1[0] = 0x07
+    half = z.copy()
+    half[:16] = 0xFF
+    word, node, wt = oracle.vocabulary_transform(tree, np.stack([f1, o, half]), 1)
+    assert list(word) == [2, 0, 2] and list(wt) == [3.5, 1.5, 3.5]
+    assert list(node) == [1, 2, 1]                     # the node at level L - 1
+    _, node0, _ = oracle.vocabulary_transform(tree, np.stack([f1, o, half]), 0)
+    assert list(node0) == [4, 0, 4]                    # level 2: the leaf itself; B stops at level 1 -> stays 0

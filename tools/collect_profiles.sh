@@ -27,4 +27,5 @@ timeout -k 10 300 python3 tools/config5_pairs.py > "$OUT/config5_pairs.json" 2>/
 timeout -k 10 300 python3 tools/stereo_rate.py > "$OUT/stereo_rate.json" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/distinctive_rate.py > "$OUT/distinctive_rate.json" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bow_rate.py > "$OUT/bow_rate.json" 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/voc_rate.py > "$OUT/voc_rate.json" 2>/dev/null || exit 1
 echo collected
