@@ -2,6 +2,8 @@
 // of an explicit pair list.  ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1744-1760 of the
 // reference) is a popcount of a XOR; the top-2 bookkeeping is the inner loop of SearchByBoW
 // (src/ORBmatcher.cc:217-242): best and second start at 256, strict '<', first index wins.
+#include <algorithm>
+
 #include "orbx_internal.h"
 
 // A (distance, row) pair packed as distance<<16 | row-in-chunk orders exactly like the reference's
@@ -307,5 +309,175 @@ hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_ch
                                                     d_children, d_word_id, d_weight, depth,
                                                     reinterpret_cast<const uint32_t *>(d_feat), n, levelsup, d_word,
                                                     d_node, d_wt);
+    return hipGetLastError();
+}
+
+// ---- brute-force top-2 on the matrix cores ----
+// With bits mapped to +-1, the dot product of two 256-bit descriptors is 256 - 2 * distance, so the
+// distances of 32 database rows against 32 queries are one 32x32x256 integer matrix product: eight
+// v_mfma_i32_32x32x32_i8.  The database operand carries +-64 and the query operand +-127, so a result
+// is 8128 * dot with room below it (dots differ by at least 2, i.e. 16256) for a row code that the
+// accumulator input adds for free: results come out of the matrix core as sortable keys
+//     key = 8128 * dot + rowcode,   rowcode = 31 - (row inside the tile) + 32 * (tiles processed since),
+// larger key = smaller distance, and among equal distances the earlier row.  Every lane holds one query
+// (the column) and 16 rows of a tile, so the top-2 bookkeeping is a max and a median-of-three per
+// result; before a new tile the two running keys move up by 32, which keeps earlier rows ahead.
+// A workgroup expands each tile of database rows from bits to bytes once, into LDS in operand order,
+// for its four waves (64 queries each, held as operands in registers for the whole sweep).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define MF_DB_C 64      // database bytes are +-64
+#define MF_Q_C 127      // query bytes are +-127
+#define MF_UNIT (MF_DB_C * MF_Q_C)        // 8128: key step per unit of dot
+#define MF_STEP (2 * MF_UNIT)             // 16256: key step between neighbouring distances
+#define MF_OFFS (MF_UNIT * 256)           // key + MF_OFFS = MF_STEP * (256 - distance) + rowcode
+#define MF_NONE (-(1 << 30))              // running key of "no row yet"
+#define MF_INVALID (-(1 << 29))           // accumulator input of rows behind the end of the database
+#define MF_MAX_CHUNK 16192                // rows per chunk: the row code must stay below MF_STEP
+
+__device__ __forceinline__ int mf_med3(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// 16 descriptor bits -> 16 bytes of +-c (lut = byte 0: -c, byte 1: +c)
+__device__ __forceinline__ v4i mf_expand16(uint32_t bits, uint32_t lut)
+{
+    v4i out;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const uint32_t nib = (bits >> (4 * n)) & 0xfu;
+        const uint32_t sel = __umul24(nib, 0x00204081u) & 0x01010101u;  // bit i of the nibble -> byte i
+        out[n] = (int)__builtin_amdgcn_perm(0u, lut, sel);
+    }
+    return out;
+}
+
+__global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ q, int nq,
+                                                   const uint32_t *__restrict__ db, long long ndb, int chunk_rows,
+                                                   uint2 *__restrict__ partial)
+{
+    __shared__ __attribute__((aligned(16))) v4i tile[2][8 * 64];  // [buffer][step * 64 + operand lane]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const uint32_t lut_q = ((uint32_t)(-MF_Q_C) & 0xffu) | ((uint32_t)MF_Q_C << 8);
+    const uint32_t lut_d = ((uint32_t)(-MF_DB_C) & 0xffu) | ((uint32_t)MF_DB_C << 8);
+    // the wave's 2 x 32 queries as B operands of the 8 k-steps
+    const int qbase = blockIdx.x * 256 + wv * 64;
+    v4i bq[2][8];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int qi = qbase + 32 * t + col;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const uint32_t w = qi < nq ? q[(size_t)qi * 8 + s] : 0u;
+            bq[t][s] = mf_expand16((w >> (16 * half)) & 0xffffu, lut_q);
+        }
+    }
+    const bool wave_active = qbase < nq;
+    const long long row0 = (long long)blockIdx.y * chunk_rows;
+    const int rows = (int)min((long long)chunk_rows, ndb - row0);
+    const int ntiles = (rows + 31) / 32;
+    // accumulator input of a full tile: register reg of this lane is row (reg&3) + 8*(reg>>2) + 4*half
+    v16i cfull;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++)
+        cfull[reg] = 31 - ((reg & 3) + 8 * (reg >> 2) + 4 * half);
+    int k1[2] = {MF_NONE, MF_NONE}, k2[2] = {MF_NONE, MF_NONE};
+
+    // expansion of one tile of database rows: thread = (row tid & 31, dword tid >> 5)
+    auto expand_tile = [&](int t, int buf) {
+        const int r = tid & 31, s = tid >> 5;
+        const int row = 32 * t + r;
+        const uint32_t w = row < rows ? db[(size_t)(row0 + row) * 8 + s] : 0u;
+        tile[buf][s * 64 + r] = mf_expand16(w & 0xffffu, lut_d);
+        tile[buf][s * 64 + 32 + r] = mf_expand16(w >> 16, lut_d);
+    };
+    if (ntiles > 0)
+        expand_tile(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles)
+            expand_tile(t + 1, buf ^ 1);
+        if (wave_active) {
+            v16i c = cfull;
+            if (32 * t + 32 > rows) {  // the last tile of the database: rows behind its end never win
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++)
+                    if (32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * half >= rows)
+                        c[reg] = MF_INVALID;
+            }
+            v16i acc0 = c, acc1 = c;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const v4i a = tile[buf][s * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+            }
+            k1[0] += 32, k2[0] += 32, k1[1] += 32, k2[1] += 32;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                k2[0] = mf_med3(k1[0], k2[0], acc0[reg]);  // k1 >= k2: the median is the new runner-up
+                k1[0] = max(k1[0], acc0[reg]);
+                k2[1] = mf_med3(k1[1], k2[1], acc1[reg]);
+                k1[1] = max(k1[1], acc1[reg]);
+            }
+        }
+        __syncthreads();
+    }
+    if (!wave_active)
+        return;
+    // the two lanes of a query (rows 4*half + ...) merge; keys of different rows are distinct
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int o1 = __shfl_xor(k1[t], 32, 64), o2 = __shfl_xor(k2[t], 32, 64);
+        const int hi = max(k1[t], o1), lo = min(k1[t], o1);
+        const int second = max(lo, max(k2[t], o2));
+        const int qi = qbase + 32 * t + col;
+        if (half == 0 && qi < nq) {
+            // key + MF_OFFS = MF_STEP * (256 - distance) + rowcode; row = 32*(ntiles-1) + 31 - rowcode
+            auto decode = [&](int key) -> uint32_t {
+                if (key < -MF_OFFS + MF_STEP)  // distance 256 (never a best match) or no row at all
+                    return TOP2_INIT;
+                const uint32_t v = (uint32_t)(key + MF_OFFS);
+                const uint32_t u = v / MF_STEP, rc = v - u * MF_STEP;
+                return ((256u - u) << 16) | (uint32_t)(32 * (ntiles - 1) + 31 - (int)rc);
+            };
+            partial[(size_t)blockIdx.y * nq + qi] = make_uint2(decode(hi), decode(second));
+        }
+    }
+}
+
+// rows per chunk of the matrix-core kernel: whole tiles, at most MF_MAX_CHUNK, about 1024 workgroups
+void orbx_top2_mfma_chunks(int nq, int64_t ndb, int *chunk_rows, int *nchunks)
+{
+    const int qblocks = (nq + 255) / 256;
+    const int want = std::max(1, 1024 / qblocks);
+    int64_t rows = (ndb + want - 1) / want;
+    rows = std::max<int64_t>(512, std::min<int64_t>(rows, MF_MAX_CHUNK));
+    rows = (rows + 31) / 32 * 32;
+    *chunk_rows = (int)rows;
+    *nchunks = (int)((ndb + rows - 1) / rows);
+}
+
+hipError_t orbx_launch_top2_mfma(const uint8_t *d_q, int nq, const uint8_t *d_db, int64_t ndb, int64_t idx_base,
+                                 uint32_t *d_partial, int chunk_rows, int nchunks, int32_t *d_best, uint16_t *d_d1,
+                                 uint16_t *d_d2, hipStream_t s)
+{
+    if (nchunks > 0) {
+        k_top2_mfma<<<dim3((nq + 255) / 256, nchunks), 256, 0, s>>>(reinterpret_cast<const uint32_t *>(d_q), nq,
+                                                                    reinterpret_cast<const uint32_t *>(d_db),
+                                                                    (long long)ndb, chunk_rows,
+                                                                    reinterpret_cast<uint2 *>(d_partial));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    k_top2_merge<<<(nq + 3) / 4, 256, 0, s>>>(reinterpret_cast<const uint2 *>(d_partial), nq, nchunks, chunk_rows,
+                                              (long long)idx_base, d_best, d_d1, d_d2);
     return hipGetLastError();
 }

@@ -976,6 +976,7 @@ struct orbx_matcher {
     // one allocation carved into the arrays of a SearchByBoW call
     uint8_t *d_ws;
     size_t ws_cap;
+    bool force_valu;  // brute-force top-2 on the vector ALUs even for large query sets (ORBX_TOP2=valu)
 };
 
 extern "C" int orbx_matcher_create(int device, int max_queries, orbx_matcher **out)
@@ -992,6 +993,10 @@ extern "C" int orbx_matcher_create(int device, int max_queries, orbx_matcher **o
     memset(m, 0, sizeof(*m));
     m->device = device;
     m->max_queries = max_queries;
+    {
+        const char *mode = getenv("ORBX_TOP2");  // "valu": keep the vector-ALU kernel (comparison runs)
+        m->force_valu = mode && strcmp(mode, "valu") == 0;
+    }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
     m->stream = m->own_stream;
@@ -1068,14 +1073,24 @@ extern "C" int orbx_match_top2_device(orbx_matcher *m, const uint8_t *d_queries,
     if (idx_base + ndb > INT32_MAX)
         return ORBX_E_ARG;
     HIP_TRY(hipSetDevice(m->device));
+    // 32 queries fill a matrix-core tile; below that the vector kernel (one query per lane) does less work
+    const bool mfma = nq >= 32 && !m->force_valu;
     int chunk_rows = 256, nchunks = 0;
-    if (ndb > 0)
-        top2_chunks(nq, ndb, &chunk_rows, &nchunks);
+    if (ndb > 0) {
+        if (mfma)
+            orbx_top2_mfma_chunks(nq, ndb, &chunk_rows, &nchunks);
+        else
+            top2_chunks(nq, ndb, &chunk_rows, &nchunks);
+    }
     int rc = grow(&m->d_partial, &m->partial_cap, (size_t)std::max(nchunks, 1) * nq * 2, m->stream);
     if (rc != ORBX_OK)
         return rc;
-    HIP_TRY(orbx_launch_top2(d_queries, nq, d_db, ndb, idx_base, m->d_partial, chunk_rows, nchunks, d_best_idx, d_d1,
-                             d_d2, m->stream));
+    if (mfma)
+        HIP_TRY(orbx_launch_top2_mfma(d_queries, nq, d_db, ndb, idx_base, m->d_partial, chunk_rows, nchunks, d_best_idx,
+                                      d_d1, d_d2, m->stream));
+    else
+        HIP_TRY(orbx_launch_top2(d_queries, nq, d_db, ndb, idx_base, m->d_partial, chunk_rows, nchunks, d_best_idx, d_d1,
+                                 d_d2, m->stream));
     return ORBX_OK;
 }
 

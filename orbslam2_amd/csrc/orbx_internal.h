@@ -155,5 +155,9 @@ hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_d
                                    int npairs, int cap0, float min_x, float max_x, float min_y, float max_y,
                                    const float *d_prev_in, float *d_prev_out, int window, float ratio, int check_ori,
                                    int *d_matches12, int *d_nmatches, int *d_pair_count, hipStream_t s);
+void orbx_top2_mfma_chunks(int nq, int64_t ndb, int *chunk_rows, int *nchunks);
+hipError_t orbx_launch_top2_mfma(const uint8_t *d_q, int nq, const uint8_t *d_db, int64_t ndb, int64_t idx_base,
+                                 uint32_t *d_partial, int chunk_rows, int nchunks, int32_t *d_best, uint16_t *d_d1,
+                                 uint16_t *d_d2, hipStream_t s);
 hipError_t orbx_launch_pair_dist(const uint8_t *d_a, const uint8_t *d_b, const int *d_pairs, int n, uint16_t *d_out,
                                  hipStream_t s);
