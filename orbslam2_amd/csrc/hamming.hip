@@ -3,6 +3,7 @@
 // reference) is a popcount of a XOR; the top-2 bookkeeping is the inner loop of SearchByBoW
 // (src/ORBmatcher.cc:217-242): best and second start at 256, strict '<', first index wins.
 #include <algorithm>
+#include <cstdlib>
 
 #include "orbx_internal.h"
 
@@ -323,7 +324,7 @@ hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_ch
 // (the column) and 16 rows of a tile, so the top-2 bookkeeping is a max and a median-of-three per
 // result; before a new tile the two running keys move up by 32, which keeps earlier rows ahead.
 // A workgroup expands each tile of database rows from bits to bytes once, into LDS in operand order,
-// for its four waves (64 queries each, held as operands in registers for the whole sweep).
+// for its four waves (128 queries each, held as operands in registers for the whole sweep).
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -335,6 +336,8 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #define MF_NONE (-(1 << 30))              // running key of "no row yet"
 #define MF_INVALID (-(1 << 29))           // accumulator input of rows behind the end of the database
 #define MF_MAX_CHUNK 16192                // rows per chunk: the row code must stay below MF_STEP
+#define MF_QT 4                           // 32-query tiles per wave
+#define MF_QPB (4 * 32 * MF_QT)           // queries per workgroup of four waves
 
 __device__ __forceinline__ int mf_med3(int a, int b, int c)
 {
@@ -356,20 +359,22 @@ __device__ __forceinline__ v4i mf_expand16(uint32_t bits, uint32_t lut)
     return out;
 }
 
+template <int QT>  // 32-query tiles per wave
 __global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ q, int nq,
                                                    const uint32_t *__restrict__ db, long long ndb, int chunk_rows,
                                                    uint2 *__restrict__ partial)
 {
     __shared__ __attribute__((aligned(16))) v4i tile[2][8 * 64];  // [buffer][step * 64 + operand lane]
+    __shared__ uint2 lut8[256];                                   // 8 bits -> 8 bytes of +-MF_DB_C
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const uint32_t lut_q = ((uint32_t)(-MF_Q_C) & 0xffu) | ((uint32_t)MF_Q_C << 8);
     const uint32_t lut_d = ((uint32_t)(-MF_DB_C) & 0xffu) | ((uint32_t)MF_DB_C << 8);
-    // the wave's 2 x 32 queries as B operands of the 8 k-steps
-    const int qbase = blockIdx.x * 256 + wv * 64;
-    v4i bq[2][8];
+    // the wave's QT x 32 queries as B operands of the 8 k-steps
+    const int qbase = (blockIdx.x * 4 + wv) * (32 * QT);
+    v4i bq[QT][8];
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < QT; t++) {
         const int qi = qbase + 32 * t + col;
 #pragma unroll
         for (int s = 0; s < 8; s++) {
@@ -381,50 +386,83 @@ __global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ 
     const long long row0 = (long long)blockIdx.y * chunk_rows;
     const int rows = (int)min((long long)chunk_rows, ndb - row0);
     const int ntiles = (rows + 31) / 32;
-    // accumulator input of a full tile: register reg of this lane is row (reg&3) + 8*(reg>>2) + 4*half
+    // accumulator input of a tile: register reg of this lane is row (reg&3) + 8*(reg>>2) + 4*half
     v16i cfull;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++)
         cfull[reg] = 31 - ((reg & 3) + 8 * (reg >> 2) + 4 * half);
-    int k1[2] = {MF_NONE, MF_NONE}, k2[2] = {MF_NONE, MF_NONE};
+    int k1[QT], k2[QT];
+#pragma unroll
+    for (int t = 0; t < QT; t++)
+        k1[t] = k2[t] = MF_NONE;
 
-    // expansion of one tile of database rows: thread = (row tid & 31, dword tid >> 5)
-    auto expand_tile = [&](int t, int buf) {
-        const int r = tid & 31, s = tid >> 5;
-        const int row = 32 * t + r;
-        const uint32_t w = row < rows ? db[(size_t)(row0 + row) * 8 + s] : 0u;
-        tile[buf][s * 64 + r] = mf_expand16(w & 0xffffu, lut_d);
-        tile[buf][s * 64 + 32 + r] = mf_expand16(w >> 16, lut_d);
+    // expansion of one tile of database rows: thread = (row tid & 31, dword tid >> 5), eight bits at a
+    // time through a 256-entry table of 8-byte groups.  The dword of tile t+2 is requested while tile t
+    // is multiplied, so no step waits for global memory.
+    {
+        const uint32_t lo = __umul24((uint32_t)tid & 0xfu, 0x00204081u) & 0x01010101u;
+        const uint32_t hi = __umul24((uint32_t)tid >> 4, 0x00204081u) & 0x01010101u;
+        lut8[tid] = make_uint2(__builtin_amdgcn_perm(0u, lut_d, lo), __builtin_amdgcn_perm(0u, lut_d, hi));
+    }
+    __syncthreads();
+    const int xr = tid & 31, xs = tid >> 5;
+    auto load_word = [&](int t) -> uint32_t {
+        const int row = 32 * t + xr;
+        return (t < ntiles && row < rows) ? db[(size_t)(row0 + row) * 8 + xs] : 0u;
     };
+    auto expand_word = [&](uint32_t w, int buf) {
+        const uint2 e0 = lut8[w & 0xffu], e1 = lut8[(w >> 8) & 0xffu];
+        const uint2 e2 = lut8[(w >> 16) & 0xffu], e3 = lut8[w >> 24];
+        v4i lo4, hi4;
+        lo4[0] = (int)e0.x, lo4[1] = (int)e0.y, lo4[2] = (int)e1.x, lo4[3] = (int)e1.y;
+        hi4[0] = (int)e2.x, hi4[1] = (int)e2.y, hi4[2] = (int)e3.x, hi4[3] = (int)e3.y;
+        tile[buf][xs * 64 + xr] = lo4;
+        tile[buf][xs * 64 + 32 + xr] = hi4;
+    };
+    uint32_t w_next = load_word(1);
     if (ntiles > 0)
-        expand_tile(0, 0);
+        expand_word(load_word(0), 0);
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
         const int buf = t & 1;
+        const uint32_t w_after = load_word(t + 2);
         if (t + 1 < ntiles)
-            expand_tile(t + 1, buf ^ 1);
+            expand_word(w_next, buf ^ 1);
+        w_next = w_after;
         if (wave_active) {
-            v16i c = cfull;
-            if (32 * t + 32 > rows) {  // the last tile of the database: rows behind its end never win
+            // all eight operand reads are issued before the first product, so their latency is paid once
+            v4i a[8];
 #pragma unroll
-                for (int reg = 0; reg < 16; reg++)
-                    if (32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * half >= rows)
-                        c[reg] = MF_INVALID;
-            }
-            v16i acc0 = c, acc1 = c;
+            for (int s = 0; s < 8; s++)
+                a[s] = tile[buf][s * 64 + lane];
+            asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+            const bool partial_tile = 32 * t + 32 > rows;  // only the last tile of the database
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const v4i a = tile[buf][s * 64 + lane];
-                acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
-            }
-            k1[0] += 32, k2[0] += 32, k1[1] += 32, k2[1] += 32;
+            for (int u = 0; u < QT; u++) {
+                v16i acc = cfull;  // the row codes ride in as the accumulator input
 #pragma unroll
-            for (int reg = 0; reg < 16; reg++) {
-                k2[0] = mf_med3(k1[0], k2[0], acc0[reg]);  // k1 >= k2: the median is the new runner-up
-                k1[0] = max(k1[0], acc0[reg]);
-                k2[1] = mf_med3(k1[1], k2[1], acc1[reg]);
-                k1[1] = max(k1[1], acc1[reg]);
+                for (int s = 0; s < 8; s++)
+                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[u][s], acc, 0, 0, 0);
+                if (partial_tile) {  // rows behind the end of the database never win
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++)
+                        if (32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * half >= rows)
+                            acc[reg] = MF_INVALID;
+                }
+                k1[u] += 32, k2[u] += 32;
+                // most tiles bring nothing new once a few have been seen: the tile's best key of every
+                // lane is compared with the lane's runner-up first
+                int m = acc[0];
+#pragma unroll
+                for (int reg = 1; reg < 16; reg++)
+                    m = max(m, acc[reg]);
+                if (__any(m > k2[u])) {
+#pragma unroll
+                    for (int reg = 0; reg < 16; reg++) {
+                        k2[u] = mf_med3(k1[u], k2[u], acc[reg]);  // k1 >= k2: the median is the new runner-up
+                        k1[u] = max(k1[u], acc[reg]);
+                    }
+                }
             }
         }
         __syncthreads();
@@ -433,7 +471,7 @@ __global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ 
         return;
     // the two lanes of a query (rows 4*half + ...) merge; keys of different rows are distinct
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < QT; t++) {
         const int o1 = __shfl_xor(k1[t], 32, 64), o2 = __shfl_xor(k2[t], 32, 64);
         const int hi = max(k1[t], o1), lo = min(k1[t], o1);
         const int second = max(lo, max(k2[t], o2));
@@ -455,8 +493,11 @@ __global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ 
 // rows per chunk of the matrix-core kernel: whole tiles, at most MF_MAX_CHUNK, about 1024 workgroups
 void orbx_top2_mfma_chunks(int nq, int64_t ndb, int *chunk_rows, int *nchunks)
 {
-    const int qblocks = (nq + 255) / 256;
-    const int want = std::max(1, 1024 / qblocks);
+    // two workgroups per CU are resident (registers); long chunks make the skip of the top-2 update effective
+    const int qblocks = (nq + MF_QPB - 1) / MF_QPB;
+    const char *env = getenv("ORBX_TOP2_BLOCKS");  // tuning runs only
+    const int target = env ? atoi(env) : 512;
+    const int want = std::max(1, target / qblocks);
     int64_t rows = (ndb + want - 1) / want;
     rows = std::max<int64_t>(512, std::min<int64_t>(rows, MF_MAX_CHUNK));
     rows = (rows + 31) / 32 * 32;
@@ -469,7 +510,7 @@ hipError_t orbx_launch_top2_mfma(const uint8_t *d_q, int nq, const uint8_t *d_db
                                  uint16_t *d_d2, hipStream_t s)
 {
     if (nchunks > 0) {
-        k_top2_mfma<<<dim3((nq + 255) / 256, nchunks), 256, 0, s>>>(reinterpret_cast<const uint32_t *>(d_q), nq,
+        k_top2_mfma<MF_QT><<<dim3((nq + MF_QPB - 1) / MF_QPB, nchunks), 256, 0, s>>>(reinterpret_cast<const uint32_t *>(d_q), nq,
                                                                     reinterpret_cast<const uint32_t *>(d_db),
                                                                     (long long)ndb, chunk_rows,
                                                                     reinterpret_cast<uint2 *>(d_partial));
