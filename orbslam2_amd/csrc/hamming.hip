@@ -316,10 +316,11 @@ hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_ch
 // ---- brute-force top-2 on the matrix cores ----
 // With bits mapped to +-1, the dot product of two 256-bit descriptors is 256 - 2 * distance, so the
 // distances of 32 database rows against 32 queries are one 32x32x256 integer matrix product: eight
-// v_mfma_i32_32x32x32_i8.  The database operand carries +-64 and the query operand +-127, so a result
-// is 8128 * dot with room below it (dots differ by at least 2, i.e. 16256) for a row code that the
+// v_mfma_i32_32x32x32_i8.  Both operands carry +-64 (0x40 / 0xc0: one differing bit, which keeps the
+// switching activity and with it the clock drop of the matrix cores low: random +-127 operands run 17 %
+// slower), so a result is 4096 * dot with room below it (dots differ by at least 2, i.e. 8192) for a row code that the
 // accumulator input adds for free: results come out of the matrix core as sortable keys
-//     key = 8128 * dot + rowcode,   rowcode = 31 - (row inside the tile) + 32 * (tiles processed since),
+//     key = 4096 * dot + rowcode,   rowcode = 31 - (row inside the tile) + 32 * (tiles processed since),
 // larger key = smaller distance, and among equal distances the earlier row.  Every lane holds one query
 // (the column) and 16 rows of a tile, so the top-2 bookkeeping is a max and a median-of-three per
 // result; before a new tile the two running keys move up by 32, which keeps earlier rows ahead.
@@ -329,20 +330,30 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 #define MF_DB_C 64      // database bytes are +-64
-#define MF_Q_C 127      // query bytes are +-127
-#define MF_UNIT (MF_DB_C * MF_Q_C)        // 8128: key step per unit of dot
-#define MF_STEP (2 * MF_UNIT)             // 16256: key step between neighbouring distances
+#define MF_Q_C 64       // query bytes are +-64
+#define MF_UNIT (MF_DB_C * MF_Q_C)        // 4096: key step per unit of dot
+#define MF_STEP (2 * MF_UNIT)             // 8192: key step between neighbouring distances
 #define MF_OFFS (MF_UNIT * 256)           // key + MF_OFFS = MF_STEP * (256 - distance) + rowcode
 #define MF_NONE (-(1 << 30))              // running key of "no row yet"
 #define MF_INVALID (-(1 << 29))           // accumulator input of rows behind the end of the database
-#define MF_MAX_CHUNK 16192                // rows per chunk: the row code must stay below MF_STEP
+#define MF_MAX_CHUNK 8160                 // rows per chunk: the row code must stay below MF_STEP
 #define MF_QT 4                           // 32-query tiles per wave
 #define MF_QPB (4 * 32 * MF_QT)           // queries per workgroup of four waves
 
+// median of three; written in the form the compiler selects as one v_med3_i32, so that it also places
+// the wait states a vector read of a fresh matrix-core result needs (inline assembly would hide the read)
 __device__ __forceinline__ int mf_med3(int a, int b, int c)
 {
+    return max(min(a, b), min(max(a, b), c));
+}
+
+// max of three as one instruction.  The compiler does not see the reads of inline assembly when it
+// places the wait states after a matrix-core result, so the statement also takes a value computed
+// from the same results by compiler-visible code, which orders it behind that code.
+__device__ __forceinline__ int mf_max3_after(int a, int b, int c, int after)
+{
     int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c), "v"(after));
     return r;
 }
 
@@ -360,7 +371,7 @@ __device__ __forceinline__ v4i mf_expand16(uint32_t bits, uint32_t lut)
 }
 
 template <int QT>  // 32-query tiles per wave
-__global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ q, int nq,
+__global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict__ q, int nq,
                                                    const uint32_t *__restrict__ db, long long ndb, int chunk_rows,
                                                    uint2 *__restrict__ partial)
 {
@@ -397,8 +408,9 @@ __global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ 
         k1[t] = k2[t] = MF_NONE;
 
     // expansion of one tile of database rows: thread = (row tid & 31, dword tid >> 5), eight bits at a
-    // time through a 256-entry table of 8-byte groups.  The dword of tile t+2 is requested while tile t
-    // is multiplied, so no step waits for global memory.
+    // time through a 256-entry table of 8-byte groups.  While tile t is multiplied, tile t+2 is expanded
+    // into the buffer tile t came from and its dword for tile t+3 is requested, and the operands of
+    // tile t+1 are read behind the last products that use those of tile t: no step waits for memory.
     {
         const uint32_t lo = __umul24((uint32_t)tid & 0xfu, 0x00204081u) & 0x01010101u;
         const uint32_t hi = __umul24((uint32_t)tid >> 4, 0x00204081u) & 0x01010101u;
@@ -419,53 +431,79 @@ __global__ __launch_bounds__(256) void k_top2_mfma(const uint32_t *__restrict__ 
         tile[buf][xs * 64 + xr] = lo4;
         tile[buf][xs * 64 + 32 + xr] = hi4;
     };
-    uint32_t w_next = load_word(1);
     if (ntiles > 0)
         expand_word(load_word(0), 0);
+    if (ntiles > 1)
+        expand_word(load_word(1), 1);
+    uint32_t w_next = load_word(2);
     __syncthreads();
-    for (int t = 0; t < ntiles; t++) {
+    v4i a[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        a[s] = tile[0][s * 64 + lane];
+    __syncthreads();  // buffer 0 is rewritten in the first step
+
+    // One tile against the wave's QT x 32 queries, in straight-line code: the products of query tile u
+    // run in the matrix pipeline while the vector ALU folds the results of tile u-1 into the running
+    // top-2.  cin is the accumulator input (row codes; MF_INVALID for rows behind the end).
+    auto step = [&](int t, const v16i &cin) {
         const int buf = t & 1;
-        const uint32_t w_after = load_word(t + 2);
-        if (t + 1 < ntiles)
-            expand_word(w_next, buf ^ 1);
+        const uint32_t w_after = load_word(t + 3);
+        if (t + 2 < ntiles)
+            expand_word(w_next, buf);
         w_next = w_after;
         if (wave_active) {
-            // all eight operand reads are issued before the first product, so their latency is paid once
-            v4i a[8];
+            v16i acc[QT];
 #pragma unroll
-            for (int s = 0; s < 8; s++)
-                a[s] = tile[buf][s * 64 + lane];
-            asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-            const bool partial_tile = 32 * t + 32 > rows;  // only the last tile of the database
+            for (int u = 0; u <= QT; u++) {
+                if (u < QT) {
+                    acc[u] = cin;
 #pragma unroll
-            for (int u = 0; u < QT; u++) {
-                v16i acc = cfull;  // the row codes ride in as the accumulator input
-#pragma unroll
-                for (int s = 0; s < 8; s++)
-                    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[u][s], acc, 0, 0, 0);
-                if (partial_tile) {  // rows behind the end of the database never win
-#pragma unroll
-                    for (int reg = 0; reg < 16; reg++)
-                        if (32 * t + (reg & 3) + 8 * (reg >> 2) + 4 * half >= rows)
-                            acc[reg] = MF_INVALID;
+                    for (int s = 0; s < 8; s++) {
+                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[u][s], acc[u], 0, 0, 0);
+                        if (u == QT - 1)
+                            a[s] = tile[buf ^ 1][s * 64 + lane];  // tile t+1, complete since the last barrier
+                    }
                 }
-                k1[u] += 32, k2[u] += 32;
-                // most tiles bring nothing new once a few have been seen: the tile's best key of every
-                // lane is compared with the lane's runner-up first
-                int m = acc[0];
+                if (u > 0) {
+                    // Two results at a time: with x the running maximum, the second largest of everything
+                    // seen is the largest of the medians med3(x, a, b) and the old second (which never
+                    // exceeds x): 20 operations for 16 results.  Earlier rows stay ahead at equal
+                    // distance because the running keys move up by one tile of row codes first.
+                    int x = k1[u - 1] + 32, y = k2[u - 1] + 32;
 #pragma unroll
-                for (int reg = 1; reg < 16; reg++)
-                    m = max(m, acc[reg]);
-                if (__any(m > k2[u])) {
+                    for (int p = 0; p < 8; p += 2) {
+                        const int va = acc[u - 1][2 * p], vb = acc[u - 1][2 * p + 1];
+                        const int vc = acc[u - 1][2 * p + 2], vd = acc[u - 1][2 * p + 3];
+                        const int m0 = mf_med3(x, va, vb);
+                        x = mf_max3_after(x, va, vb, m0);
+                        const int m1 = mf_med3(x, vc, vd);
+                        x = mf_max3_after(x, vc, vd, m1);
+                        y = max(max(y, m0), m1);
+                    }
+                    k1[u - 1] = x, k2[u - 1] = y;
+                }
+                if (u > 0 && u < QT) {
 #pragma unroll
-                    for (int reg = 0; reg < 16; reg++) {
-                        k2[u] = mf_med3(k1[u], k2[u], acc[reg]);  // k1 >= k2: the median is the new runner-up
-                        k1[u] = max(k1[u], acc[reg]);
+                    for (int s = 0; s < 8; s++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one matrix product
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three vector operations
                     }
                 }
             }
         }
         __syncthreads();
+    };
+    const int nfull = rows / 32;
+    for (int t = 0; t < nfull; t++)
+        step(t, cfull);
+    if (nfull < ntiles) {
+        // the last, partial tile: rows behind the end enter with a code that never wins
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++)
+            if (32 * nfull + (reg & 3) + 8 * (reg >> 2) + 4 * half >= rows)
+                cfull[reg] = MF_INVALID;
+        step(nfull, cfull);
     }
     if (!wave_active)
         return;
