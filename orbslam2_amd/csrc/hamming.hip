@@ -377,6 +377,9 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
 {
     __shared__ __attribute__((aligned(16))) v4i tile[2][8 * 64];  // [buffer][step * 64 + operand lane]
     __shared__ uint2 lut8[256];                                   // 8 bits -> 8 bytes of +-MF_DB_C
+#ifdef MF_EXP_CLOCK
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const uint32_t lut_q = ((uint32_t)(-MF_Q_C) & 0xffu) | ((uint32_t)MF_Q_C << 8);
@@ -418,9 +421,13 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
     }
     __syncthreads();
     const int xr = tid & 31, xs = tid >> 5;
+    // byte offset of this thread's dword of tile t inside the chunk; rows behind the end of the chunk
+    // read its last row: whatever they hold never wins (MF_INVALID)
+    const char *chunk = reinterpret_cast<const char *>(db + (size_t)row0 * 8);
+    const uint32_t off_last = (uint32_t)((rows - 1) * 8 + xs) * 4u;
     auto load_word = [&](int t) -> uint32_t {
-        const int row = 32 * t + xr;
-        return (t < ntiles && row < rows) ? db[(size_t)(row0 + row) * 8 + xs] : 0u;
+        const uint32_t off = min((uint32_t)((32 * t + xr) * 8 + xs) * 4u, off_last);
+        return *reinterpret_cast<const uint32_t *>(chunk + off);
     };
     auto expand_word = [&](uint32_t w, int buf) {
         const uint2 e0 = lut8[w & 0xffu], e1 = lut8[(w >> 8) & 0xffu];
@@ -431,10 +438,8 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
         tile[buf][xs * 64 + xr] = lo4;
         tile[buf][xs * 64 + 32 + xr] = hi4;
     };
-    if (ntiles > 0)
-        expand_word(load_word(0), 0);
-    if (ntiles > 1)
-        expand_word(load_word(1), 1);
+    expand_word(load_word(0), 0);
+    expand_word(load_word(1), 1);
     uint32_t w_next = load_word(2);
     __syncthreads();
     v4i a[8];
@@ -443,55 +448,74 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
         a[s] = tile[0][s * 64 + lane];
     __syncthreads();  // buffer 0 is rewritten in the first step
 
-    // One tile against the wave's QT x 32 queries, in straight-line code: the products of query tile u
-    // run in the matrix pipeline while the vector ALU folds the results of tile u-1 into the running
-    // top-2.  cin is the accumulator input (row codes; MF_INVALID for rows behind the end).
+    // One tile against the wave's QT x 32 queries as one basic block of 8 * QT slots, one product each,
+    // in exactly this order of issue (nothing moves across a slot's end).  Beside the products of
+    // query tile u the vector ALU folds the results of the query tile before into the running top-2
+    // (those of the last one in the next step), the database tile after next is expanded (table reads
+    // behind the first products, writes one query tile later, the request for the dword of the tile
+    // after that in the third), and each operand of the next database tile is read behind the last
+    // product that uses the register it lands in.  cin is the accumulator input (row codes;
+    // MF_INVALID behind the end).
+    // The fold takes 16 results two at a time: with x the running maximum, the second largest of
+    // everything seen is the largest of the medians med3(x, a, b) and the old second (which never
+    // exceeds x): 20 operations for 16 results.  Earlier rows stay ahead at equal distance because
+    // the running keys move up by one tile of row codes first.
+    v16i pend;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++)
+        pend[reg] = MF_NONE;
+    int fx = 0, fy = 0, fm = 0;
+    auto fold_piece = [&](int i, int u, const v16i &r) {
+        if (i == 0)
+            fx = k1[u] + 32, fy = k2[u] + 32;
+        const int m = mf_med3(fx, r[2 * i], r[2 * i + 1]);
+        fx = mf_max3_after(fx, r[2 * i], r[2 * i + 1], m);
+        if (i & 1)
+            fy = max(max(fy, fm), m);
+        else
+            fm = m;
+        if (i == 7)
+            k1[u] = fx, k2[u] = fy;
+    };
     auto step = [&](int t, const v16i &cin) {
         const int buf = t & 1;
-        const uint32_t w_after = load_word(t + 3);
-        if (t + 2 < ntiles)
-            expand_word(w_next, buf);
-        w_next = w_after;
-        if (wave_active) {
-            v16i acc[QT];
+        v16i acc[QT];
+        uint2 e0, e1, e2, e3;
 #pragma unroll
-            for (int u = 0; u <= QT; u++) {
-                if (u < QT) {
-                    acc[u] = cin;
+        for (int u = 0; u < QT; u++) {
 #pragma unroll
-                    for (int s = 0; s < 8; s++) {
-                        acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[u][s], acc[u], 0, 0, 0);
-                        if (u == QT - 1)
-                            a[s] = tile[buf ^ 1][s * 64 + lane];  // tile t+1, complete since the last barrier
-                    }
+            for (int s = 0; s < 8; s++) {
+                acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[u][s], s ? acc[u] : cin, 0, 0, 0);
+                // results are read one slot after the product that wrote them: no wait for the matrix pipeline
+#pragma unroll
+                for (int i = s - 1; i >= 0 && i <= (s == 7 ? 7 : s - 1); i++) {
+                    if (u == 0)
+                        fold_piece(i, QT - 1, pend);
+                    else
+                        fold_piece(i, u - 1, acc[u - 1]);
                 }
-                if (u > 0) {
-                    // Two results at a time: with x the running maximum, the second largest of everything
-                    // seen is the largest of the medians med3(x, a, b) and the old second (which never
-                    // exceeds x): 20 operations for 16 results.  Earlier rows stay ahead at equal
-                    // distance because the running keys move up by one tile of row codes first.
-                    int x = k1[u - 1] + 32, y = k2[u - 1] + 32;
-#pragma unroll
-                    for (int p = 0; p < 8; p += 2) {
-                        const int va = acc[u - 1][2 * p], vb = acc[u - 1][2 * p + 1];
-                        const int vc = acc[u - 1][2 * p + 2], vd = acc[u - 1][2 * p + 3];
-                        const int m0 = mf_med3(x, va, vb);
-                        x = mf_max3_after(x, va, vb, m0);
-                        const int m1 = mf_med3(x, vc, vd);
-                        x = mf_max3_after(x, vc, vd, m1);
-                        y = max(max(y, m0), m1);
-                    }
-                    k1[u - 1] = x, k2[u - 1] = y;
+                if (u == 0 && s == 1)
+                    e0 = lut8[w_next & 0xffu], e1 = lut8[(w_next >> 8) & 0xffu];
+                if (u == 0 && s == 2)
+                    e2 = lut8[(w_next >> 16) & 0xffu], e3 = lut8[w_next >> 24];
+                if (u == 1 && s == 1) {
+                    v4i lo4;
+                    lo4[0] = (int)e0.x, lo4[1] = (int)e0.y, lo4[2] = (int)e1.x, lo4[3] = (int)e1.y;
+                    tile[buf][xs * 64 + xr] = lo4;
                 }
-                if (u > 0 && u < QT) {
-#pragma unroll
-                    for (int s = 0; s < 8; s++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one matrix product
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three vector operations
-                    }
+                if (u == 1 && s == 2) {
+                    v4i hi4;
+                    hi4[0] = (int)e2.x, hi4[1] = (int)e2.y, hi4[2] = (int)e3.x, hi4[3] = (int)e3.y;
+                    tile[buf][xs * 64 + 32 + xr] = hi4;
                 }
+                if (u == 2 && s == 0)
+                    w_next = load_word(t + 3);
+                if (u == QT - 1)
+                    a[s] = tile[buf ^ 1][s * 64 + lane];  // tile t+1, complete since the last barrier
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        pend = acc[QT - 1];
         __syncthreads();
     };
     const int nfull = rows / 32;
@@ -505,6 +529,16 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
                 cfull[reg] = MF_INVALID;
         step(nfull, cfull);
     }
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        fold_piece(s, QT - 1, pend);
+#ifdef MF_EXP_CLOCK
+    if (tid == 0) {
+        const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        partial[(size_t)gridDim.y * nq + blockIdx.y * gridDim.x + blockIdx.x] = make_uint2((uint32_t)(r1 - r0), (xcc << 16) | (hw & 0xffffu));
+    }
+#endif
     if (!wave_active)
         return;
     // the two lanes of a query (rows 4*half + ...) merge; keys of different rows are distinct

@@ -15,7 +15,7 @@ int main()
     uint2 *dp;
     int chunk, nchunks;
     orbx_top2_mfma_chunks(nq, ndb, &chunk, &nchunks);
-    hipMalloc(&dq, hq.size() * 4), hipMalloc(&ddb, hdb.size() * 4), hipMalloc(&dp, (size_t)nchunks * nq * 8);
+    hipMalloc(&dq, hq.size() * 4), hipMalloc(&ddb, hdb.size() * 4), hipMalloc(&dp, (size_t)nchunks * nq * 8 + nchunks * 8 * 8);
     hipMemcpy(dq, hq.data(), hq.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(ddb, hdb.data(), hdb.size() * 4, hipMemcpyHostToDevice);
     const dim3 grid((nq + MF_QPB - 1) / MF_QPB, nchunks);
@@ -33,5 +33,18 @@ int main()
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     printf("%s: %.4f ms per launch (chunk %d x %d)\n", hipGetErrorString(hipGetLastError()), ms / reps, chunk, nchunks);
+#ifdef MF_EXP_CLOCK
+    const int nwg = nchunks * grid.x;
+    std::vector<uint2> hc(nwg);
+    hipMemcpy(hc.data(), dp + (size_t)nchunks * nq, nwg * 8, hipMemcpyDeviceToHost);
+    double sx[16] = {0}; int nx[16] = {0};
+    for (int i = 0; i < nwg; i++) {
+        const int xcc = hc[i].y >> 16 & 15;
+        sx[xcc] += hc[i].x / 100.0, nx[xcc]++;
+    }
+    for (int x = 0; x < 16; x++) if (nx[x]) printf("xcc %d: %d workgroups, avg %.1f us\n", x, nx[x], sx[x] / nx[x]);
+    for (int i = 0; i < nwg; i++)
+        printf("wg %d x %d xcc %d se %d cu %d simd %d wave %d: %.1f us\n", i, i % (int)grid.x, hc[i].y >> 16 & 15, hc[i].y >> 13 & 7, hc[i].y >> 8 & 15, hc[i].y >> 4 & 3, hc[i].y & 15, hc[i].x / 100.0);
+#endif
     return 0;
 }
