@@ -377,9 +377,6 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
 {
     __shared__ __attribute__((aligned(16))) v4i tile[2][8 * 64];  // [buffer][step * 64 + operand lane]
     __shared__ uint2 lut8[256];                                   // 8 bits -> 8 bytes of +-MF_DB_C
-#ifdef MF_EXP_CLOCK
-    const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
     const uint32_t lut_q = ((uint32_t)(-MF_Q_C) & 0xffu) | ((uint32_t)MF_Q_C << 8);
@@ -532,13 +529,6 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
 #pragma unroll
     for (int s = 0; s < 8; s++)
         fold_piece(s, QT - 1, pend);
-#ifdef MF_EXP_CLOCK
-    if (tid == 0) {
-        const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
-        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20), hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        partial[(size_t)gridDim.y * nq + blockIdx.y * gridDim.x + blockIdx.x] = make_uint2((uint32_t)(r1 - r0), (xcc << 16) | (hw & 0xffffu));
-    }
-#endif
     if (!wave_active)
         return;
     // the two lanes of a query (rows 4*half + ...) merge; keys of different rows are distinct

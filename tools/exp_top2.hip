@@ -1,5 +1,5 @@
-// Timing harness for variants of the matrix-core top-2 kernel (tuning aid): includes the kernel source,
-// runs it on random descriptors and prints the average launch time.  Build with -DMF_EXP_... switches.
+// Timing harness of the matrix-core top-2 path (tuning aid): includes the kernel source, runs it on
+// random descriptors and prints the average time of a call (top-2 kernel and merge).
 #include "../orbslam2_amd/csrc/hamming.hip"
 #include <cstdio>
 #include <vector>
@@ -11,40 +11,33 @@ int main()
     uint32_t x = 12345u;
     for (auto &v : hq) v = (x = x * 1664525u + 1013904223u) ^ (x >> 13);
     for (auto &v : hdb) v = (x = x * 1664525u + 1013904223u) ^ (x >> 13);
-    uint32_t *dq, *ddb;
-    uint2 *dp;
+    uint32_t *dq, *ddb, *dp;
+    int *dbest;
+    uint16_t *dd1, *dd2;
     int chunk, nchunks;
     orbx_top2_mfma_chunks(nq, ndb, &chunk, &nchunks);
-    hipMalloc(&dq, hq.size() * 4), hipMalloc(&ddb, hdb.size() * 4), hipMalloc(&dp, (size_t)nchunks * nq * 8 + nchunks * 8 * 8);
+    hipMalloc(&dq, hq.size() * 4), hipMalloc(&ddb, hdb.size() * 4), hipMalloc(&dp, (size_t)nchunks * nq * 8);
+    hipMalloc(&dbest, nq * 4), hipMalloc(&dd1, nq * 2), hipMalloc(&dd2, nq * 2);
     hipMemcpy(dq, hq.data(), hq.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(ddb, hdb.data(), hdb.size() * 4, hipMemcpyHostToDevice);
-    const dim3 grid((nq + MF_QPB - 1) / MF_QPB, nchunks);
+    auto run = [&]() {
+        return orbx_launch_top2_mfma((const uint8_t *)dq, nq, (const uint8_t *)ddb, ndb, 0, dp, chunk, nchunks, dbest,
+                                     dd1, dd2, 0);
+    };
     for (int i = 0; i < 3; i++)
-        k_top2_mfma<MF_QT><<<grid, 256>>>(dq, nq, ddb, ndb, chunk, dp);
+        run();
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
     const int reps = 20;
     hipEventRecord(e0);
     for (int i = 0; i < reps; i++)
-        k_top2_mfma<MF_QT><<<grid, 256>>>(dq, nq, ddb, ndb, chunk, dp);
+        run();
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    printf("%s: %.4f ms per launch (chunk %d x %d)\n", hipGetErrorString(hipGetLastError()), ms / reps, chunk, nchunks);
-#ifdef MF_EXP_CLOCK
-    const int nwg = nchunks * grid.x;
-    std::vector<uint2> hc(nwg);
-    hipMemcpy(hc.data(), dp + (size_t)nchunks * nq, nwg * 8, hipMemcpyDeviceToHost);
-    double sx[16] = {0}; int nx[16] = {0};
-    for (int i = 0; i < nwg; i++) {
-        const int xcc = hc[i].y >> 16 & 15;
-        sx[xcc] += hc[i].x / 100.0, nx[xcc]++;
-    }
-    for (int x = 0; x < 16; x++) if (nx[x]) printf("xcc %d: %d workgroups, avg %.1f us\n", x, nx[x], sx[x] / nx[x]);
-    for (int i = 0; i < nwg; i++)
-        printf("wg %d x %d xcc %d se %d cu %d simd %d wave %d: %.1f us\n", i, i % (int)grid.x, hc[i].y >> 16 & 15, hc[i].y >> 13 & 7, hc[i].y >> 8 & 15, hc[i].y >> 4 & 3, hc[i].y & 15, hc[i].x / 100.0);
-#endif
+    printf("%s: %.4f ms per call, top-2 kernel and merge (chunk %d x %d)\n", hipGetErrorString(hipGetLastError()), ms / reps,
+           chunk, nchunks);
     return 0;
 }
