@@ -39,7 +39,7 @@ VALU_LANE_OPS_MEASURED = 36.0e12
 OPS_PER_PAIR = 16
 # The top-2 kernel runs on the matrix cores for 32 or more queries: a pair is 256 int8 multiply-adds of
 # v_mfma_i32_32x32x32_i8 (32 cycles per instruction and SIMD: 1024 MAC per clock and SIMD, 1024 SIMDs, 2.4 GHz);
-# tools/ubench_mfma_i8.hip sustains 2.12e15 MAC/s with operands in registers
+# tools/ubench_mfma_i8.hip sustains 2.12e15 MAC/s with random +-64 operands in registers (1.8e15 with +-127)
 MFMA_I8_MAC_PER_S = 1024 * 1024 * 2.4e9
 MFMA_I8_MAC_MEASURED = 2.124e15
 MAC_PER_PAIR = 256
