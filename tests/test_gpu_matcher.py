@@ -63,6 +63,29 @@ def test_top2_ties_and_extremes(oracle):
     assert list(best) == [-1, -1, -1] and list(d1) == [256] * 3
 
 
+@pytest.mark.parametrize("ndb,nq", [(31, 32), (32, 33), (33, 127), (63, 128), (545, 129), (8159, 40), (8160, 513),
+                                    (8161, 64), (16325, 96), (20000, 1100)])
+def test_top2_matrix_core_path_ties_at_tile_and_chunk_borders(oracle, ndb, nq):
+    """32 queries or more run on the matrix cores: 32-row tiles, 16 rows per lane, chunks of whole tiles.
+    Rows drawn from a pool of 40 descriptors tie all the time, so the first index has to win across
+    lanes, tiles and chunks, and the second distance often equals the first."""
+    rng = np.random.default_rng(ndb * 7 + nq)
+    pool = orbx.synth_descriptors(3, 40)
+    db = pool[rng.integers(0, 40, size=ndb)]
+    q = pool[rng.integers(0, 40, size=nq)].copy()
+    for i in range(0, nq, 3):                      # some queries a few bits off their pool row
+        bits = np.unpackbits(q[i])
+        bits[rng.choice(256, size=int(rng.integers(1, 9)), replace=False)] ^= 1
+        q[i] = np.packbits(bits)
+    q[-1] = ~db[0]                                   # distance 256 to row 0
+    m = orbx.ORBmatcher(0.75)
+    best, d1, d2 = m.match_top2(q, db)
+    ob, o1, o2 = oracle.match_top2(q, db)
+    assert np.array_equal(best, ob)
+    assert np.array_equal(d1, o1)
+    assert np.array_equal(d2, o2)
+
+
 def test_sharded_merge_equals_single_pass(oracle):
     db, q = make_db(50000, 500, seed=5)
     m = orbx.ORBmatcher(0.75)
