@@ -264,6 +264,17 @@ int orbx_features_in_area_device(orbx_matcher *m, const orbx_keypoint *d_keypoin
                                  float min_y, float max_y, const int32_t *d_cell_start, const int32_t *d_cell_items,
                                  const float *d_x, const float *d_y, const float *d_r, const int32_t *d_min_level,
                                  const int32_t *d_max_level, int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n);
+/* Frame::UndistortKeyPoints (src/Frame.cc:467-499): cv::undistortPoints(pts, pts, mK, mDistCoef, Mat(), mK)
+ * on the positions of n keypoints; the other fields are copied, so d_out is mvKeysUn.  cam = fx, fy, cx,
+ * cy of mK; dist = k1, k2, p1, p2 and, with ndist == 5, k3 (mDistCoef).  As in the reference (:469-473),
+ * dist[0] == 0 copies the keypoints unchanged.  d_out may equal d_keypoints.  Device pointers,
+ * asynchronous on the matcher's stream. */
+int orbx_undistort_keypoints_device(orbx_matcher *m, const orbx_keypoint *d_keypoints, int n, const float *cam,
+                                    const float *dist, int ndist, orbx_keypoint *d_out);
+/* The same on n (x, y) float pairs in host memory; with the four image corners it is the first half of
+ * Frame::ComputeImageBounds (:503-517), whose min/max of the results the caller takes. */
+int orbx_undistort_points(orbx_matcher *m, const float *xy, int n, const float *cam, const float *dist, int ndist,
+                          float *xy_out);
 /* Both steps from host arrays (keypoints and queries in, lists out); cell_start / cell_items may be
  * NULL when the grid itself is not wanted. */
 int orbx_features_in_area(orbx_matcher *m, const orbx_keypoint *keypoints, int n, float min_x, float max_x, float min_y,

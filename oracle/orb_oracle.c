@@ -1008,6 +1008,40 @@ void orc_grid_queries(const orc_keypoint *kps, int n, float min_x, float max_x, 
     orc_grid_free(&g);
 }
 
+/* Frame::UndistortKeyPoints (src/Frame.cc:467-499) and the corner pass of Frame::ComputeImageBounds
+ * (:503-517): cv::undistortPoints(points, points, K, distCoef, Mat(), K) on float points.  OpenCV is not
+ * part of the reference tree; this restates its published point routine for the call the reference
+ * makes (no rectification, new camera matrix = K, default iteration count): the pixel goes to the
+ * normalised plane, five fixed-point iterations of the radial (k1, k2, k3) and tangential (p1, p2)
+ * model remove the distortion, K maps the result back; all in double, inputs and results float.
+ * cam = fx, fy, cx, cy (the float entries of mK); dist = k1, k2, p1, p2[, k3] (mDistCoef, 4 or 5 floats).
+ * With dist[0] == 0 the reference copies the points (:469-473). */
+void orc_undistort_points(const float *xy, int n, const float *cam, const float *dist, int ndist, float *out)
+{
+    if (dist[0] == 0.0f) {
+        memcpy(out, xy, sizeof(float) * 2 * (size_t)n);
+        return;
+    }
+    const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k1 = dist[0], k2 = dist[1], p1 = dist[2], p2 = dist[3], k3 = ndist > 4 ? dist[4] : 0.;
+    for (int i = 0; i < n; i++) {
+        double x = xy[2 * i], y = xy[2 * i + 1];
+        const double x0 = x = (x - cx) * ifx;
+        const double y0 = y = (y - cy) * ify;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = 1. / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+            const double dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+            const double dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+            x = (x0 - dx) * icdist;
+            y = (y0 - dy) * icdist;
+        }
+        out[2 * i] = (float)(fx * x + cx);
+        out[2 * i + 1] = (float)(fy * y + cy);
+    }
+}
+
 /* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1698-1739 */
 void orc_three_maxima(const int *hist_sizes, int L, int *ind1, int *ind2, int *ind3)
 {

@@ -327,6 +327,19 @@ def grid_queries(kps, bounds, x, y, r, min_level, max_level, cap=512):
     return [out[q, :cnt[q]].copy() for q in range(nq)], cs, ci[:cs[-1]].copy()
 
 
+def undistort_points(xy, cam, dist):
+    """cv::undistortPoints(xy, xy, K, dist, Mat(), K) as Frame::UndistortKeyPoints calls it: (n, 2) float32."""
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    cam = np.ascontiguousarray(cam, np.float32)
+    dist = np.ascontiguousarray(dist, np.float32)
+    out = np.zeros_like(xy)
+    fn = lib().orc_undistort_points
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    fn(_p(xy), len(xy), _p(cam), _p(dist), len(dist), _p(out))
+    return out
+
+
 def vocabulary_transform(tree, feat, levelsup):
     """tree = dict(desc (N,32) uint8, child_start (N+1,) int32, children int32, word_id (N,) int32,
     weight (N,) float64, L).  Returns (word, node, weight) per feature."""

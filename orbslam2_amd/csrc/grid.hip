@@ -148,3 +148,63 @@ hipError_t orbx_launch_features_in_area(const orbx_keypoint *d_kp, float min_x, 
                                          d_out_idx, d_out_n, a);
     return hipGetLastError();
 }
+
+// Frame::UndistortKeyPoints (src/Frame.cc:467-499): cv::undistortPoints with the camera matrix as the
+// new projection, one thread per point, in double like the library routine: normalise, five fixed-point
+// iterations of the radial/tangential model, project back.  The keypoint's other fields are copied.
+struct UndistortArgs {
+    double fx, fy, cx, cy, k1, k2, p1, p2, k3;
+};
+
+__device__ __forceinline__ float2 undistort_point(float px, float py, const UndistortArgs &a)
+{
+    const double ifx = 1. / a.fx, ify = 1. / a.fy;
+    double x = px, y = py;
+    const double x0 = x = (x - a.cx) * ifx;
+    const double y0 = y = (y - a.cy) * ify;
+#pragma unroll 1
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((a.k3 * r2 + a.k2) * r2 + a.k1) * r2);
+        const double dx = 2 * a.p1 * x * y + a.p2 * (r2 + 2 * x * x);
+        const double dy = a.p1 * (r2 + 2 * y * y) + 2 * a.p2 * x * y;
+        x = (x0 - dx) * icdist;
+        y = (y0 - dy) * icdist;
+    }
+    return make_float2((float)(a.fx * x + a.cx), (float)(a.fy * y + a.cy));
+}
+
+__global__ __launch_bounds__(256) void k_undistort_keypoints(const orbx_keypoint *__restrict__ kp, int n,
+                                                             orbx_keypoint *__restrict__ out, UndistortArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    orbx_keypoint k = kp[i];
+    const float2 u = undistort_point(k.x, k.y, a);
+    k.x = u.x, k.y = u.y;
+    out[i] = k;
+}
+
+__global__ __launch_bounds__(256) void k_undistort_points(const float2 *__restrict__ xy, int n, float2 *__restrict__ out,
+                                                          UndistortArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+        out[i] = undistort_point(xy[i].x, xy[i].y, a);
+}
+
+// cam = fx, fy, cx, cy; dist = k1, k2, p1, p2[, k3]; exactly one of (d_kp, d_kp_out) and (d_xy, d_xy_out) is used
+hipError_t orbx_launch_undistort(const orbx_keypoint *d_kp, orbx_keypoint *d_kp_out, const float *d_xy, float *d_xy_out,
+                                 int n, const float *cam, const float *dist, int ndist, hipStream_t s)
+{
+    if (n <= 0)
+        return hipSuccess;
+    UndistortArgs a{cam[0], cam[1], cam[2], cam[3], dist[0], dist[1], dist[2], dist[3], ndist > 4 ? dist[4] : 0.f};
+    if (d_kp)
+        k_undistort_keypoints<<<(n + 255) / 256, 256, 0, s>>>(d_kp, n, d_kp_out, a);
+    else
+        k_undistort_points<<<(n + 255) / 256, 256, 0, s>>>(reinterpret_cast<const float2 *>(d_xy), n,
+                                                           reinterpret_cast<float2 *>(d_xy_out), a);
+    return hipGetLastError();
+}

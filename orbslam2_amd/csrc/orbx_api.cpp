@@ -1553,6 +1553,48 @@ extern "C" int orbx_features_in_area(orbx_matcher *m, const orbx_keypoint *keypo
     return ORBX_OK;
 }
 
+extern "C" int orbx_undistort_keypoints_device(orbx_matcher *m, const orbx_keypoint *d_keypoints, int n, const float *cam,
+                                               const float *dist, int ndist, orbx_keypoint *d_out)
+{
+    if (!m || n < 0 || !cam || !dist || (ndist != 4 && ndist != 5) || (n > 0 && (!d_keypoints || !d_out)))
+        return ORBX_E_ARG;
+    if (n == 0)
+        return ORBX_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    if (dist[0] == 0.0f) {
+        if (d_out != d_keypoints)
+            HIP_TRY(hipMemcpyAsync(d_out, d_keypoints, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToDevice,
+                                   m->stream));
+        return ORBX_OK;
+    }
+    HIP_TRY(orbx_launch_undistort(d_keypoints, d_out, nullptr, nullptr, n, cam, dist, ndist, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_undistort_points(orbx_matcher *m, const float *xy, int n, const float *cam, const float *dist,
+                                     int ndist, float *xy_out)
+{
+    if (!m || n < 0 || !cam || !dist || (ndist != 4 && ndist != 5) || (n > 0 && (!xy || !xy_out)))
+        return ORBX_E_ARG;
+    if (n == 0)
+        return ORBX_OK;
+    if (dist[0] == 0.0f) {
+        if (xy_out != xy)
+            memmove(xy_out, xy, (size_t)n * 2 * sizeof(float));
+        return ORBX_OK;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = grow(&m->d_ws, &m->ws_cap, (size_t)n * 2 * sizeof(float), m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    float *d = reinterpret_cast<float *>(m->d_ws);
+    HIP_TRY(hipMemcpyAsync(d, xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(orbx_launch_undistort(nullptr, nullptr, d, d, n, cam, dist, ndist, m->stream));
+    HIP_TRY(hipMemcpyAsync(xy_out, d, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const float *angle1, const uint8_t *valid1,
                                   const int32_t *feat_start, int nb, const int32_t *node_kf_start,
                                   const int32_t *node_ids1, const int32_t *node_start1, const int32_t *node_items1,

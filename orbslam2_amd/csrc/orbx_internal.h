@@ -147,6 +147,8 @@ hipError_t orbx_launch_features_in_area(const orbx_keypoint *d_kp, float min_x, 
                                         const int32_t *d_cell_start, const int32_t *d_cell_items, const float *d_qx,
                                         const float *d_qy, const float *d_qr, const int *d_qmin, const int *d_qmax,
                                         int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n, hipStream_t s);
+hipError_t orbx_launch_undistort(const orbx_keypoint *d_kp, orbx_keypoint *d_kp_out, const float *d_xy, float *d_xy_out,
+                                 int n, const float *cam, const float *dist, int ndist, hipStream_t s);
 hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_child_start, const int *d_children,
                                      const int *d_word_id, const double *d_weight, int depth, const uint8_t *d_feat,
                                      int n, int levelsup, int *d_word, int *d_node, double *d_wt, hipStream_t s);

@@ -187,6 +187,41 @@ class ORBmatcher:
         per_kf = [m12[feat_start[b]:feat_start[b + 1]].copy() for b in range(nb)]
         return nm[:nb].copy(), per_kf, m21[:nb, :n2].copy()
 
+    def UndistortKeyPoints(self, keypoints, cam, dist):
+        """Frame::UndistortKeyPoints (src/Frame.cc:467-499): keypoints = KEYPOINT_DTYPE array (mvKeys), cam = (fx,
+        fy, cx, cy) of mK, dist = mDistCoef (k1, k2, p1, p2[, k3]).  Returns mvKeysUn."""
+        kps = np.ascontiguousarray(keypoints, L.KEYPOINT_DTYPE).copy()
+        xy = np.ascontiguousarray(np.stack([kps["x"], kps["y"]], axis=1), np.float32)
+        out = self.undistort_points(xy, cam, dist)
+        kps["x"], kps["y"] = out[:, 0], out[:, 1]
+        return kps
+
+    def undistort_points(self, xy, cam, dist):
+        """cv::undistortPoints(xy, xy, mK, mDistCoef, Mat(), mK) on an (n, 2) float32 array."""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        cam = np.ascontiguousarray(cam, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        out = np.zeros_like(xy)
+        L.check(self._lib.orbx_undistort_points(self._handle(), L.ptr(xy), len(xy), L.ptr(cam), L.ptr(dist), len(dist),
+                                                L.ptr(out)), "orbx_undistort_points")
+        return out
+
+    def ComputeImageBounds(self, cols, rows, cam, dist):
+        """Frame::ComputeImageBounds (src/Frame.cc:501-531): (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+        dist = np.ascontiguousarray(dist, np.float32)
+        if dist[0] == 0.0:
+            return 0.0, float(cols), 0.0, float(rows)
+        c = self.undistort_points(np.array([[0, 0], [cols, 0], [0, rows], [cols, rows]], np.float32), cam, dist)
+        return (float(min(c[0, 0], c[2, 0])), float(max(c[1, 0], c[3, 0])), float(min(c[0, 1], c[1, 1])),
+                float(max(c[2, 1], c[3, 1])))
+
+    def undistort_keypoints_device(self, d_keypoints, n, cam, dist, d_out):
+        """Device form: d_keypoints / d_out are device pointers to n orbx_keypoint records (may be equal)."""
+        cam = np.ascontiguousarray(cam, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        L.check(self._lib.orbx_undistort_keypoints_device(self._handle(), d_keypoints, n, L.ptr(cam), L.ptr(dist),
+                                                          len(dist), d_out), "orbx_undistort_keypoints_device")
+
     def GetFeaturesInArea(self, keypoints, bounds, x, y, r, min_level, max_level, cap=512):
         """Frame::AssignFeaturesToGrid + Frame::GetFeaturesInArea (src/Frame.cc:239-253, 349-420) for a batch of
         queries: keypoints = KEYPOINT_DTYPE array (mvKeysUn), bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY),

@@ -403,3 +403,43 @@ def test_vocabulary_transform_vs_oracle(oracle):
     bad["children"][-1] = 0
     with pytest.raises(orbx.OrbxError):
         orbx.ORBVocabulary(bad["desc"], bad["child_start"], bad["children"], bad["word_id"], bad["weight"], 4)
+
+
+@pytest.mark.parametrize("dist", [(-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05),        # EuRoC.yaml
+                                  (0.262383, -0.953104, -0.005358, 0.002628, 1.163314),         # TUM1.yaml
+                                  (0.0, 0.0, 0.0, 0.0)])                                         # KITTI: no distortion
+def test_undistort_keypoints_vs_oracle(oracle, dist):
+    """Frame::UndistortKeyPoints / ComputeImageBounds with the shipped camera models: the arithmetic is
+    double with the oracle's operation order, so the float results must be equal bit for bit."""
+    import torch
+    rng = np.random.default_rng(11)
+    n = 3000
+    kps = np.zeros(n, orbx.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, 752, n).astype(np.float32)
+    kps["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    kps["size"], kps["angle"], kps["octave"], kps["class_id"] = 31, rng.uniform(0, 360, n), rng.integers(0, 8, n), -1
+    cam = (458.654, 457.296, 367.215, 248.375) if len(dist) == 4 else (517.306408, 516.469215, 318.643040, 255.313989)
+    m = orbx.ORBmatcher()
+    un = m.UndistortKeyPoints(kps, cam, dist)
+    want = oracle.undistort_points(np.stack([kps["x"], kps["y"]], 1), cam, dist)
+    assert np.array_equal(un["x"], want[:, 0]) and np.array_equal(un["y"], want[:, 1])
+    for f in ("size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(un[f], kps[f])
+    if dist[0] == 0:
+        assert np.array_equal(un["x"], kps["x"])
+    else:
+        assert np.abs(un["x"] - kps["x"]).max() > 1.0      # the model moves points near the border by pixels
+    # device form, in place
+    d = torch.from_numpy(kps.view(np.uint8).reshape(n, -1).copy()).cuda()
+    m.undistort_keypoints_device(d.data_ptr(), n, cam, dist, d.data_ptr())
+    torch.cuda.synchronize()
+    got = d.cpu().numpy().reshape(-1).view(orbx.KEYPOINT_DTYPE)
+    assert np.array_equal(got["x"], want[:, 0]) and np.array_equal(got["y"], want[:, 1])
+    assert np.array_equal(got["octave"], kps["octave"])
+    # image bounds: min / max of the undistorted corners (src/Frame.cc:503-523)
+    b = m.ComputeImageBounds(752, 480, cam, dist)
+    c = oracle.undistort_points(np.array([[0, 0], [752, 0], [0, 480], [752, 480]], np.float32), cam, dist)
+    if dist[0] == 0:
+        assert b == (0.0, 752.0, 0.0, 480.0)
+    else:
+        assert b == (min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1]))

@@ -368,3 +368,30 @@ def test_vocabulary_transform_known_answer(oracle):
     assert list(node) == [1, 2, 1]                     # the node at level L - 1
     _, node0, _ = oracle.vocabulary_transform(tree, np.stack([f1, o, half]), 0)
     assert list(node0) == [4, 0, 4]                    # level 2: the leaf itself; B stops at level 1 -> stays 0
+
+
+def test_undistort_points_known_answers():
+    """cv::undistortPoints as Frame::UndistortKeyPoints calls it: the principal point is a fixed point,
+    zero k1 copies the input (src/Frame.cc:469-473), and re-applying the forward distortion model to
+    the result reproduces the input pixel."""
+    from oracle import pyoracle as orc
+    cam = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    dist = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)
+    pp = np.array([[cam[2], cam[3]]], np.float32)
+    assert np.array_equal(orc.undistort_points(pp, cam, dist), pp)
+    rng = np.random.default_rng(4)
+    xy = np.stack([rng.uniform(100, 650, 500), rng.uniform(60, 420, 500)], 1).astype(np.float32)
+    assert np.array_equal(orc.undistort_points(xy, cam, np.zeros(4, np.float32)), xy)
+    for d in (dist, np.array([0.262383, -0.953104, -0.005358, 0.002628, 1.163314], np.float32)):
+        un = orc.undistort_points(xy, cam, d).astype(np.float64)
+        k1, k2, p1, p2 = (float(v) for v in d[:4])
+        k3 = float(d[4]) if len(d) > 4 else 0.0
+        x = (un[:, 0] - float(cam[2])) / float(cam[0])
+        y = (un[:, 1] - float(cam[3])) / float(cam[1])
+        r2 = x * x + y * y
+        rad = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+        xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        back = np.stack([xd * float(cam[0]) + float(cam[2]), yd * float(cam[1]) + float(cam[3])], 1)
+        # five iterations leave a residual that grows towards the image border: well below a pixel here
+        assert np.abs(back - xy).max() < 0.2 and np.median(np.abs(back - xy)) < 1e-3
