@@ -390,22 +390,40 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
 
 
 def cpu_baseline(host_frames, w, nfeat, budget_s):
-    """The oracle (scalar C restatement of the reference extractor) on one host core, same frames."""
+    """The oracle (scalar C restatement of the reference extractor) on one host core, same frames; then the
+    same frame-parallel on the host cores this process may use (the reference runs one thread per image:
+    src/Frame.cc:79-82), reported beside it."""
+    import concurrent.futures
+
     from oracle import pyoracle as orc
 
     orc.lib()
+    imgs = [np.ascontiguousarray(f[:, :w]) for f in host_frames[:64]]
+
+    def one(i):
+        orc.extract(imgs[i % len(imgs)], nfeat, 1.2, 8, 20, 7)  # ctypes releases the GIL during the call
+
     n = 0
     t0 = time.perf_counter()
     while True:
-        img = np.ascontiguousarray(host_frames[n % len(host_frames)][:, :w])
-        orc.extract(img, nfeat, 1.2, 8, 20, 7)
+        one(n)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 2000:
+        if dt >= budget_s * 0.6 or n >= 2000:
             break
-    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d KITTI-shape synthetic frames in %.1f s, one thread, scalar C (no SIMD FAST/resize/blur "
-                      "as OpenCV has, so pessimistic for the reference)" % (n, dt)}
+    res = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d KITTI-shape synthetic frames in %.1f s, one thread, scalar C (no SIMD FAST/resize/blur "
+                     "as OpenCV has, so pessimistic for the reference)" % (n, dt)}
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    if threads > 1:
+        want = max(threads, int(res["value"] * threads * budget_s * 0.4))
+        t0 = time.perf_counter()
+        with concurrent.futures.ThreadPoolExecutor(threads) as pool:
+            list(pool.map(one, range(want)))
+        dt = time.perf_counter() - t0
+        res["frame_parallel"] = {"value": round(want / dt, 2), "unit": "frames/s", "cores": threads,
+                                 "sample": "%d frames in %.1f s, one frame per thread" % (want, dt)}
+    return res
 
 
 if __name__ == "__main__":
