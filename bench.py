@@ -98,6 +98,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ORBX_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers, all-gather) even
+    # with one rank, to rehearse it with the nccl backend on a one-GPU box
+    dist_path = world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
     import torch
     import torch.distributed as dist
 
@@ -108,7 +111,7 @@ def main():
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")  # "gloo" rehearses the N>1 path on one GPU
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -147,7 +150,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_path:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +168,7 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     el = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-    if world > 1:
+    if dist_path:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     n_kp = float(np.mean(np.concatenate([e.batch_counts()[0] for e in exs])))
@@ -182,13 +185,13 @@ def main():
     launch_frames = eyes[0][1]
 
     hamming_sharded = None
-    if world > 1 and not args.no_hamming:
+    if dist_path and not args.no_hamming:
         try:
             hamming_sharded = bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev)
         except Exception as exc:  # the frames/s line must survive a failure of this extra measurement
             hamming_sharded = {"error": repr(exc)}
     if rank != 0:
-        if world > 1:
+        if dist_path:
             dist.destroy_process_group()
         return
 
@@ -232,15 +235,15 @@ def main():
                         "%d instances on %d streams, blur overlapped" % (ninst, 2 * ninst),
     }
 
-    if world == 1 and not args.no_hamming:
+    if not dist_path and not args.no_hamming:
         out["hamming"] = bench_hamming(orbx, torch, stream)
-    if world > 1 and hamming_sharded is not None:
+    if dist_path and hamming_sharded is not None:
         out["hamming"] = hamming_sharded
-    if world == 1 and not args.no_cpu_baseline:
+    if not dist_path and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host, w, nfeat, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_path:
         dist.destroy_process_group()
 
 
