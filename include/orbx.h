@@ -264,6 +264,32 @@ int orbx_features_in_area_device(orbx_matcher *m, const orbx_keypoint *d_keypoin
                                  float min_y, float max_y, const int32_t *d_cell_start, const int32_t *d_cell_items,
                                  const float *d_x, const float *d_y, const float *d_r, const int32_t *d_min_level,
                                  const int32_t *d_max_level, int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n);
+/* ORBmatcher::SearchByProjection in the two forms the tracking thread runs on every frame:
+ *   use_second = 1: (Frame &F, const vector<MapPoint*> &vpMapPoints, th), src/ORBmatcher.cc:46-137;
+ *   use_second = 0: (Frame &CurrentFrame, const Frame &LastFrame, th, bMono), :1412-1566, with its
+ *                   rotation check when check_orientation is set.
+ * The frame: n <= 32768 keypoints (mvKeysUn) with descriptors, uright = mvuRight or NULL (monocular),
+ * taken[i] != 0 where mvpMapPoints[i] has Observations() > 0 (NULL: none), the grid bounds.
+ * The ns sources, in the reference's order, after what precedes the window query there: valid[s] = the
+ * source is searched at all (mbTrackInView and not bad, :55-59; a last-frame map point that is no outlier
+ * and projects inside the image, :1438-1462; NULL: all), (x, y) = projection, r = window radius
+ * (r * mvScaleFactors[level] of :67-72; th * mvScaleFactors[octave] of :1465), min_level / max_level =
+ * the level arguments of GetFeaturesInArea (:72, :1469-1474; max_level -1 = open), xr = predicted right
+ * coordinate (mTrackProjXR; u - mbf * invzc) or NULL with uright NULL, src_desc = the map points'
+ * descriptors, blocks[s] != 0 where the source's map point has Observations() > 0, so that the feature
+ * it wins is skipped by later sources (NULL: all), src_angle = mvKeysUn[i].angle of the last frame
+ * (used with check_orientation only).  th_dist = TH_HIGH; nnratio as in the matcher.
+ * Results: match[s] = feature index or -1; feature_match[i] = last source written to feature i, -1 if
+ * none, -2 if the rotation check cleared it (:1553); *nmatches as the reference returns it.  A window
+ * holding more than 256 candidates returns ORBX_E_CAPACITY. */
+int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *keypoints, const uint8_t *descriptors,
+                              const float *uright, const uint8_t *taken, int n, float min_x, float max_x, float min_y,
+                              float max_y, const uint8_t *valid, const float *x, const float *y, const float *r,
+                              const int32_t *min_level, const int32_t *max_level, const float *xr,
+                              const uint8_t *src_desc, const uint8_t *blocks, const float *src_angle, int ns,
+                              int use_second, float nnratio, int th_dist, int check_orientation, int32_t *match,
+                              int32_t *feature_match, int32_t *nmatches);
+
 /* Frame::UndistortKeyPoints (src/Frame.cc:467-499): cv::undistortPoints(pts, pts, mK, mDistCoef, Mat(), mK)
  * on the positions of n keypoints; the other fields are copied, so d_out is mvKeysUn.  cam = fx, fy, cx,
  * cy of mK; dist = k1, k2, p1, p2 and, with ndist == 5, k3 (mDistCoef).  As in the reference (:469-473),

@@ -1504,3 +1504,104 @@ int orc_distinctive_descriptor(const uint8_t *desc, int n)
 }
 
 int orc_trace_sizeof(void) { return (int)sizeof(orc_trace); }
+
+/* ORBmatcher::SearchByProjection, the two forms the tracking thread runs on every frame:
+ *   use_second = 1: (Frame &F, const vector<MapPoint*>&, th), src/ORBmatcher.cc:46-137 - best and second
+ *                   best with their levels, accepted if best <= th_dist unless both lie on one level and
+ *                   best > nnratio * second (:118-126);
+ *   use_second = 0: (Frame &CurrentFrame, const Frame &LastFrame, th, bMono), :1412-1566 - best only
+ *                   (:1500-1520), then the rotation histogram with factor HISTO_LENGTH/360.0f (:1421,
+ *                   :1528-1560) when check_orientation is set.
+ * The caller has done what precedes the window query: source s is skipped unless valid[s] (mbTrackInView
+ * and not bad; or a last-frame map point that is no outlier and projects into the image), (x, y) is the
+ * projection, r the window radius (r * mvScaleFactors[level], resp. th * mvScaleFactors[octave]),
+ * min_level / max_level the level window of GetFeaturesInArea, xr the predicted right coordinate that a
+ * feature with uright > 0 must meet within r (:89-94, :1488-1494).
+ * taken[i] != 0: feature i holds a map point with Observations() > 0 and is skipped (:84-86, :1483-1485).
+ * An accepted match writes the feature's map point (:127, :1522): later sources skip that feature iff
+ * blocks[s] (the source's map point has observations).  match[s] = feature or -1; feature_match[i] = the
+ * last source written to feature i, -1 if none, -2 if the rotation check cleared it (:1553); returns nmatches. */
+int orc_search_by_projection(const orc_keypoint *kps, const uint8_t *desc, const float *uright, const uint8_t *taken_in,
+                             int n, float min_x, float max_x, float min_y, float max_y, const uint8_t *valid,
+                             const float *x, const float *y, const float *r, const int *min_level, const int *max_level,
+                             const float *xr, const uint8_t *src_desc, const uint8_t *blocks, const float *src_angle,
+                             int ns, int use_second, float nnratio, int th_dist, int check_orientation, int *match,
+                             int *feature_match)
+{
+    enum { HISTO_LENGTH = 30 };
+    orc_grid g;
+    orc_grid_build(&g, kps, n, min_x, max_x, min_y, max_y);
+    uint8_t *taken = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int *cand = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    int *bin_of = (int *)malloc(sizeof(int) * (size_t)(ns > 0 ? ns : 1));
+    int hist[HISTO_LENGTH] = {0};
+    if (taken_in)
+        memcpy(taken, taken_in, (size_t)n);
+    for (int i = 0; i < n; i++)
+        feature_match[i] = -1;
+    const float factor = HISTO_LENGTH / 360.0f;
+    int nmatches = 0;
+    for (int s = 0; s < ns; s++) {
+        match[s] = -1;
+        bin_of[s] = -1;
+        if (valid && !valid[s])
+            continue;
+        const int nc = orc_features_in_area(&g, kps, x[s], y[s], r[s], min_level[s], max_level[s], cand);
+        if (nc == 0)
+            continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (taken[idx])
+                continue;
+            if (uright && uright[idx] > 0) {
+                const float er = fabsf(xr[s] - uright[idx]);
+                if (er > r[s])
+                    continue;
+            }
+            const int dist = orc_descriptor_distance(src_desc + (size_t)s * 32, desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = kps[idx].octave;
+                bestIdx = idx;
+            } else if (use_second && dist < bestDist2) {
+                bestLevel2 = kps[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        if (bestDist <= th_dist) {
+            if (use_second && bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2)
+                continue;
+            match[s] = bestIdx;
+            feature_match[bestIdx] = s;
+            taken[bestIdx] = blocks ? (blocks[s] != 0) : 1;
+            nmatches++;
+            if (check_orientation) {
+                float rot = src_angle[s] - kps[bestIdx].angle;
+                if (rot < 0.0)
+                    rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH)
+                    bin = 0;
+                bin_of[s] = bin;
+                hist[bin]++;
+            }
+        }
+    }
+    if (check_orientation) {
+        int i1, i2, i3;
+        orc_three_maxima(hist, HISTO_LENGTH, &i1, &i2, &i3);
+        for (int s = 0; s < ns; s++) {
+            const int b = bin_of[s];
+            if (b >= 0 && b != i1 && b != i2 && b != i3) {
+                feature_match[match[s]] = -2;
+                nmatches--;
+            }
+        }
+    }
+    free(taken), free(cand), free(bin_of);
+    orc_grid_free(&g);
+    return nmatches;
+}

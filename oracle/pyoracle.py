@@ -327,6 +327,33 @@ def grid_queries(kps, bounds, x, y, r, min_level, max_level, cap=512):
     return [out[q, :cnt[q]].copy() for q in range(nq)], cs, ci[:cs[-1]].copy()
 
 
+def search_by_projection(kps, desc, bounds, x, y, r, min_level, max_level, src_desc, nnratio, *, uright=None,
+                         taken=None, valid=None, xr=None, blocks=None, src_angle=None, use_second=True, th_dist=100,
+                         check_orientation=False):
+    """ORBmatcher::SearchByProjection, both tracking forms: (nmatches, match per source, feature_match)."""
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+    n, ns = len(kps), len(x)
+    f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+    u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+    ur, tk, va, xr_, bl, an = f32(uright), u8(taken), u8(valid), f32(xr), u8(blocks), f32(src_angle)
+    qx, qy, qr = f32(x), f32(y), f32(r)
+    lo, hi = np.ascontiguousarray(min_level, np.int32), np.ascontiguousarray(max_level, np.int32)
+    sd = np.ascontiguousarray(src_desc, np.uint8).reshape(-1, 32)
+    match = np.full(max(ns, 1), -1, np.int32)
+    fmatch = np.full(max(n, 1), -1, np.int32)
+    opt = lambda a: None if a is None else _p(a)
+    fn = lib().orc_search_by_projection
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                   C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    nm = fn(_p(kps), _p(desc), opt(ur), opt(tk), n, bounds[0], bounds[1], bounds[2], bounds[3], opt(va), _p(qx), _p(qy),
+            _p(qr), _p(lo), _p(hi), opt(xr_), _p(sd), opt(bl), opt(an), ns, int(use_second), nnratio, th_dist,
+            int(check_orientation), _p(match), _p(fmatch))
+    return int(nm), match[:ns].copy(), fmatch[:n].copy()
+
+
 def undistort_points(xy, cam, dist):
     """cv::undistortPoints(xy, xy, K, dist, Mat(), K) as Frame::UndistortKeyPoints calls it: (n, 2) float32."""
     xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)

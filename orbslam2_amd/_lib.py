@@ -90,6 +90,9 @@ SIGNATURES = {
                                                _P, _P, C.c_int, C.c_int, _P, _P]),
     "orbx_features_in_area": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, _P,
                                         _P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "orbx_search_by_projection": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P,
+                                            _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                            _P, _P, _P]),
     "orbx_undistort_keypoints_device": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "orbx_undistort_points": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "orbx_search_by_bow": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P,

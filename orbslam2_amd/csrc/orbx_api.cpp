@@ -1553,6 +1553,86 @@ extern "C" int orbx_features_in_area(orbx_matcher *m, const orbx_keypoint *keypo
     return ORBX_OK;
 }
 
+extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *keypoints, const uint8_t *descriptors,
+                                         const float *uright, const uint8_t *taken, int n, float min_x, float max_x,
+                                         float min_y, float max_y, const uint8_t *valid, const float *x, const float *y,
+                                         const float *r, const int32_t *min_level, const int32_t *max_level,
+                                         const float *xr, const uint8_t *src_desc, const uint8_t *blocks,
+                                         const float *src_angle, int ns, int use_second, float nnratio, int th_dist,
+                                         int check_orientation, int32_t *match, int32_t *feature_match,
+                                         int32_t *nmatches)
+{
+    const int cap = 256;
+    if (!m || n < 0 || n > 32768 || ns < 0 || !nmatches || (n > 0 && (!keypoints || !descriptors || !feature_match)) ||
+        (ns > 0 && (!x || !y || !r || !min_level || !max_level || !src_desc || !match)) || (uright && !xr) ||
+        (check_orientation && ns > 0 && !src_angle))
+        return ORBX_E_ARG;
+    *nmatches = 0;
+    HIP_TRY(hipSetDevice(m->device));
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        const size_t at = off;
+        off += (std::max<size_t>(bytes, 4) + 255) / 256 * 256;
+        return at;
+    };
+    const size_t o_kp = carve((size_t)n * sizeof(orbx_keypoint)), o_desc = carve((size_t)n * 32);
+    const size_t o_ur = carve((size_t)n * 4), o_tk = carve((size_t)n), o_cs = carve((size_t)(64 * 48 + 1) * 4);
+    const size_t o_ci = carve((size_t)n * 4), o_fm = carve((size_t)n * 4);
+    const size_t o_va = carve((size_t)ns), o_x = carve((size_t)ns * 4), o_y = carve((size_t)ns * 4);
+    const size_t o_r = carve((size_t)ns * 4), o_lo = carve((size_t)ns * 4), o_hi = carve((size_t)ns * 4);
+    const size_t o_xr = carve((size_t)ns * 4), o_sd = carve((size_t)ns * 32), o_bl = carve((size_t)ns);
+    const size_t o_an = carve((size_t)ns * 4), o_list = carve((size_t)ns * cap * 4), o_cnt = carve((size_t)ns * 4);
+    const size_t o_ent = carve((size_t)ns * cap * 4), o_m = carve((size_t)ns * 4), o_res = carve(8);
+    int rc = grow(&m->d_ws, &m->ws_cap, off, m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    uint8_t *w = m->d_ws;
+    auto up = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
+        return (bytes && src) ? hipMemcpyAsync(w + at, src, bytes, hipMemcpyHostToDevice, m->stream) : hipSuccess;
+    };
+    HIP_TRY(up(o_kp, keypoints, (size_t)n * sizeof(orbx_keypoint)));
+    HIP_TRY(up(o_desc, descriptors, (size_t)n * 32));
+    HIP_TRY(up(o_ur, uright, (size_t)n * 4));
+    HIP_TRY(up(o_tk, taken, (size_t)n));
+    HIP_TRY(up(o_va, valid, (size_t)ns));
+    HIP_TRY(up(o_x, x, (size_t)ns * 4));
+    HIP_TRY(up(o_y, y, (size_t)ns * 4));
+    HIP_TRY(up(o_r, r, (size_t)ns * 4));
+    HIP_TRY(up(o_lo, min_level, (size_t)ns * 4));
+    HIP_TRY(up(o_hi, max_level, (size_t)ns * 4));
+    HIP_TRY(up(o_xr, xr, (size_t)ns * 4));
+    HIP_TRY(up(o_sd, src_desc, (size_t)ns * 32));
+    HIP_TRY(up(o_bl, blocks, (size_t)ns));
+    HIP_TRY(up(o_an, src_angle, (size_t)ns * 4));
+    const orbx_keypoint *d_kp = (const orbx_keypoint *)(w + o_kp);
+    rc = orbx_frame_grid_build_device(m, d_kp, n, min_x, max_x, min_y, max_y, (int32_t *)(w + o_cs), (int32_t *)(w + o_ci));
+    if (rc != ORBX_OK)
+        return rc;
+    rc = orbx_features_in_area_device(m, d_kp, min_x, max_x, min_y, max_y, (const int32_t *)(w + o_cs),
+                                      (const int32_t *)(w + o_ci), (const float *)(w + o_x), (const float *)(w + o_y),
+                                      (const float *)(w + o_r), (const int32_t *)(w + o_lo), (const int32_t *)(w + o_hi), ns,
+                                      cap, (int32_t *)(w + o_list), (int32_t *)(w + o_cnt));
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(orbx_launch_search_by_projection(
+        d_kp, w + o_desc, uright ? (const float *)(w + o_ur) : nullptr, taken ? w + o_tk : nullptr, n,
+        valid ? w + o_va : nullptr, (const float *)(w + o_r), xr ? (const float *)(w + o_xr) : nullptr, w + o_sd,
+        blocks ? w + o_bl : nullptr, src_angle ? (const float *)(w + o_an) : nullptr, ns, (const int32_t *)(w + o_list),
+        (const int32_t *)(w + o_cnt), cap, (uint32_t *)(w + o_ent), use_second, nnratio, th_dist, check_orientation,
+        (int32_t *)(w + o_m), (int32_t *)(w + o_fm), (int32_t *)(w + o_res), m->stream));
+    int32_t res[2] = {0, 0};
+    if (ns > 0)
+        HIP_TRY(hipMemcpyAsync(match, w + o_m, (size_t)ns * 4, hipMemcpyDeviceToHost, m->stream));
+    if (n > 0)
+        HIP_TRY(hipMemcpyAsync(feature_match, w + o_fm, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(res, w + o_res, 8, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (res[1])
+        return ORBX_E_CAPACITY;
+    *nmatches = res[0];
+    return ORBX_OK;
+}
+
 extern "C" int orbx_undistort_keypoints_device(orbx_matcher *m, const orbx_keypoint *d_keypoints, int n, const float *cam,
                                                const float *dist, int ndist, orbx_keypoint *d_out)
 {

@@ -147,6 +147,13 @@ hipError_t orbx_launch_features_in_area(const orbx_keypoint *d_kp, float min_x, 
                                         const int32_t *d_cell_start, const int32_t *d_cell_items, const float *d_qx,
                                         const float *d_qy, const float *d_qr, const int *d_qmin, const int *d_qmax,
                                         int nq, int cap, int32_t *d_out_idx, int32_t *d_out_n, hipStream_t s);
+hipError_t orbx_launch_search_by_projection(const orbx_keypoint *d_kp, const uint8_t *d_desc, const float *d_uright,
+                                            const uint8_t *d_taken, int n, const uint8_t *d_valid, const float *d_r,
+                                            const float *d_xr, const uint8_t *d_src_desc, const uint8_t *d_blocks,
+                                            const float *d_src_angle, int ns, const int32_t *d_list,
+                                            const int32_t *d_count, int cap, uint32_t *d_entry, int use_second,
+                                            float nnratio, int th_dist, int check_orientation, int32_t *d_match,
+                                            int32_t *d_feature_match, int32_t *d_result, hipStream_t s);
 hipError_t orbx_launch_undistort(const orbx_keypoint *d_kp, orbx_keypoint *d_kp_out, const float *d_xy, float *d_xy_out,
                                  int n, const float *cam, const float *dist, int ndist, hipStream_t s);
 hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_child_start, const int *d_children,

@@ -187,6 +187,65 @@ class ORBmatcher:
         per_kf = [m12[feat_start[b]:feat_start[b + 1]].copy() for b in range(nb)]
         return nm[:nb].copy(), per_kf, m21[:nb, :n2].copy()
 
+    def search_by_projection(self, keypoints, descriptors, bounds, x, y, r, min_level, max_level, src_desc, *,
+                             uright=None, taken=None, valid=None, xr=None, blocks=None, src_angle=None,
+                             use_second=True, th_dist=100, check_orientation=False):
+        """The window search both tracking forms of ORBmatcher::SearchByProjection share (src/ORBmatcher.cc:46-137,
+        :1412-1566); arguments as orbx_search_by_projection in include/orbx.h.  Returns (nmatches, match per
+        source, feature_match per frame feature: source index, -1 none, -2 cleared by the rotation check)."""
+        kps = np.ascontiguousarray(keypoints, L.KEYPOINT_DTYPE)
+        desc = np.ascontiguousarray(descriptors, np.uint8).reshape(-1, 32)
+        n, ns = len(kps), len(x)
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, np.float32)
+        u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        ur, tk, va, xr_, bl, an = f32(uright), u8(taken), u8(valid), f32(xr), u8(blocks), f32(src_angle)
+        qx, qy, qr, lo, hi = f32(x), f32(y), f32(r), i32(min_level), i32(max_level)
+        sd = np.ascontiguousarray(src_desc, np.uint8).reshape(-1, 32)
+        match = np.full(max(ns, 1), -1, np.int32)
+        fmatch = np.full(max(n, 1), -1, np.int32)
+        nm = C.c_int32(0)
+        opt = lambda a: None if a is None else L.ptr(a)
+        L.check(self._lib.orbx_search_by_projection(
+            self._handle(), L.ptr(kps), L.ptr(desc), opt(ur), opt(tk), n, bounds[0], bounds[1], bounds[2], bounds[3],
+            opt(va), L.ptr(qx), L.ptr(qy), L.ptr(qr), L.ptr(lo), L.ptr(hi), opt(xr_), L.ptr(sd), opt(bl), opt(an), ns,
+            int(bool(use_second)), float(self.mfNNratio), int(th_dist), int(bool(check_orientation)), L.ptr(match),
+            L.ptr(fmatch), C.byref(nm)), "orbx_search_by_projection")
+        return int(nm.value), match[:ns].copy(), fmatch[:n].copy()
+
+    def SearchByProjectionMapPoints(self, keypoints, descriptors, bounds, scale_factors, track_in_view, proj_x, proj_y,
+                                    scale_level, view_cos, mp_desc, th=1.0, *, uright=None, proj_xr=None, taken=None,
+                                    blocks=None):
+        """ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, th)
+        (src/ORBmatcher.cc:46-137): the per-map-point fields are mbTrackInView && !isBad, mTrackProjX, mTrackProjY,
+        mnTrackScaleLevel, mTrackViewCos, GetDescriptor(), mTrackProjXR."""
+        lvl = np.ascontiguousarray(scale_level, np.int32)
+        r = np.where(np.asarray(view_cos, np.float32) > np.float32(0.998), np.float32(2.5), np.float32(4.0))
+        if th != 1.0:
+            r = r * np.float32(th)
+        r = (r.astype(np.float32) * np.asarray(scale_factors, np.float32)[lvl]).astype(np.float32)
+        return self.search_by_projection(keypoints, descriptors, bounds, proj_x, proj_y, r, lvl - 1, lvl, mp_desc,
+                                         uright=uright, taken=taken, valid=track_in_view, xr=proj_xr, blocks=blocks,
+                                         use_second=True, th_dist=self.TH_HIGH)
+
+    def SearchByProjectionLastFrame(self, keypoints, descriptors, bounds, scale_factors, valid, u, v, last_octave,
+                                    last_angle, mp_desc, th, *, forward=False, backward=False, uright=None, ur=None,
+                                    taken=None, blocks=None, check_orientation=True):
+        """ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)
+        (src/ORBmatcher.cc:1412-1566) from the projections (u, v[, ur]) of the last frame's map points: valid =
+        has a map point, no outlier, in front of the camera and inside the image bounds (:1438-1462)."""
+        octv = np.ascontiguousarray(last_octave, np.int32)
+        r = (np.float32(th) * np.asarray(scale_factors, np.float32)[octv]).astype(np.float32)
+        if forward:
+            lo, hi = octv, np.full_like(octv, -1)
+        elif backward:
+            lo, hi = np.zeros_like(octv), octv
+        else:
+            lo, hi = octv - 1, octv + 1
+        return self.search_by_projection(keypoints, descriptors, bounds, u, v, r, lo, hi, mp_desc, uright=uright,
+                                         taken=taken, valid=valid, xr=ur, blocks=blocks, src_angle=last_angle,
+                                         use_second=False, th_dist=self.TH_HIGH, check_orientation=check_orientation)
+
     def UndistortKeyPoints(self, keypoints, cam, dist):
         """Frame::UndistortKeyPoints (src/Frame.cc:467-499): keypoints = KEYPOINT_DTYPE array (mvKeys), cam = (fx,
         fy, cx, cy) of mK, dist = mDistCoef (k1, k2, p1, p2[, k3]).  Returns mvKeysUn."""

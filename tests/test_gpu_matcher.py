@@ -443,3 +443,89 @@ def test_undistort_keypoints_vs_oracle(oracle, dist):
         assert b == (0.0, 752.0, 0.0, 480.0)
     else:
         assert b == (min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1]))
+
+
+def _projection_scene(seed, n=2500, ns=1800, stereo=True):
+    """A frame of n features and ns sources cut from them: projections a few pixels off, descriptors a few
+    bits off, levels around the feature's; clusters of sources aim at the same feature so that the
+    first-come exclusion decides, some features hold a map point already, some sources do not block."""
+    rng = np.random.default_rng(seed)
+    kps = np.zeros(n, orbx.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(0, 1241, n).astype(np.float32)
+    kps["y"] = rng.uniform(0, 376, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kps["size"], kps["class_id"] = 31, -1
+    desc = orbx.synth_descriptors(seed, n)
+    uright = np.where(rng.random(n) < 0.6, kps["x"] - rng.uniform(1, 60, n), -1).astype(np.float32) if stereo else None
+    taken = (rng.random(n) < 0.15).astype(np.uint8)
+    src = rng.integers(0, n, ns)
+    src[1::7] = src[0:-1:7][:len(src[1::7])]          # neighbours in the list aim at the same feature
+    x = (kps["x"][src] + rng.normal(0, 3, ns)).astype(np.float32)
+    y = (kps["y"][src] + rng.normal(0, 3, ns)).astype(np.float32)
+    lvl = np.clip(kps["octave"][src] + rng.integers(-1, 2, ns), 0, 7).astype(np.int32)
+    sd = desc[src].copy()
+    for i in range(ns):
+        bits = np.unpackbits(sd[i])
+        bits[rng.choice(256, size=int(rng.integers(0, 70)), replace=False)] ^= 1
+        sd[i] = np.packbits(bits)
+    xr = (x - (kps["x"][src] - np.where(uright[src] > 0, uright[src], 0)) + rng.normal(0, 2, ns)).astype(np.float32) \
+        if stereo else None
+    valid = (rng.random(ns) < 0.9).astype(np.uint8)
+    blocks = (rng.random(ns) < 0.85).astype(np.uint8)
+    angle = ((kps["angle"][src] + rng.normal(0, 6, ns) + np.where(rng.random(ns) < 0.1, 140, 0)) % 360).astype(np.float32)
+    view_cos = rng.uniform(0.99, 1.0, ns).astype(np.float32)
+    return dict(kps=kps, desc=desc, uright=uright, taken=taken, x=x, y=y, lvl=lvl, sd=sd, xr=xr, valid=valid,
+                blocks=blocks, angle=angle, view_cos=view_cos)
+
+
+@pytest.mark.parametrize("stereo,th", [(True, 1.0), (False, 3.0), (True, 5.0)])
+def test_search_by_projection_map_points_vs_oracle(oracle, stereo, th):
+    """src/ORBmatcher.cc:46-137 (TrackLocalMap): matches, feature assignments and the count equal the oracle's."""
+    sc = _projection_scene(21 + int(th), stereo=stereo)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    m = orbx.ORBmatcher(0.8)
+    nm, match, fm = m.SearchByProjectionMapPoints(sc["kps"], sc["desc"], bounds, scale, sc["valid"], sc["x"], sc["y"],
+                                                  sc["lvl"], sc["view_cos"], sc["sd"], th, uright=sc["uright"],
+                                                  proj_xr=sc["xr"], taken=sc["taken"], blocks=sc["blocks"])
+    r = np.where(sc["view_cos"] > np.float32(0.998), np.float32(2.5), np.float32(4.0))
+    if th != 1.0:
+        r = r * np.float32(th)
+    r = (r.astype(np.float32) * scale[sc["lvl"]]).astype(np.float32)
+    onm, omatch, ofm = oracle.search_by_projection(sc["kps"], sc["desc"], bounds, sc["x"], sc["y"], r, sc["lvl"] - 1,
+                                                   sc["lvl"], sc["sd"], 0.8, uright=sc["uright"], taken=sc["taken"],
+                                                   valid=sc["valid"], xr=sc["xr"], blocks=sc["blocks"], use_second=True)
+    assert nm == onm and nm > 300
+    assert np.array_equal(match, omatch) and np.array_equal(fm, ofm)
+    assert (match[sc["valid"] == 0] == -1).all()
+    assert (sc["taken"][match[match >= 0]] == 0).all()
+
+
+@pytest.mark.parametrize("mode,ori", [("none", True), ("forward", True), ("backward", False)])
+def test_search_by_projection_last_frame_vs_oracle(oracle, mode, ori):
+    """src/ORBmatcher.cc:1412-1566 (TrackWithMotionModel): best-only search, level window by motion direction,
+    rotation histogram with factor HISTO_LENGTH/360."""
+    sc = _projection_scene(31, stereo=(mode != "none"))
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    m = orbx.ORBmatcher(0.9)
+    nm, match, fm = m.SearchByProjectionLastFrame(sc["kps"], sc["desc"], bounds, scale, sc["valid"], sc["x"], sc["y"],
+                                                  sc["lvl"], sc["angle"], sc["sd"], 7.0, forward=mode == "forward",
+                                                  backward=mode == "backward", uright=sc["uright"], ur=sc["xr"],
+                                                  taken=sc["taken"], blocks=sc["blocks"], check_orientation=ori)
+    r = (np.float32(7.0) * scale[sc["lvl"]]).astype(np.float32)
+    if mode == "forward":
+        lo, hi = sc["lvl"], np.full_like(sc["lvl"], -1)
+    elif mode == "backward":
+        lo, hi = np.zeros_like(sc["lvl"]), sc["lvl"]
+    else:
+        lo, hi = sc["lvl"] - 1, sc["lvl"] + 1
+    onm, omatch, ofm = oracle.search_by_projection(sc["kps"], sc["desc"], bounds, sc["x"], sc["y"], r, lo, hi, sc["sd"],
+                                                   0.9, uright=sc["uright"], taken=sc["taken"], valid=sc["valid"],
+                                                   xr=sc["xr"], blocks=sc["blocks"], src_angle=sc["angle"],
+                                                   use_second=False, check_orientation=ori)
+    assert nm == onm and nm > 300
+    assert np.array_equal(match, omatch) and np.array_equal(fm, ofm)
+    if ori:
+        assert (fm == -2).sum() > 10        # the planted 140-degree rotations fall outside the three maxima

@@ -395,3 +395,62 @@ def test_undistort_points_known_answers():
         back = np.stack([xd * float(cam[0]) + float(cam[2]), yd * float(cam[1]) + float(cam[3])], 1)
         # five iterations leave a residual that grows towards the image border: well below a pixel here
         assert np.abs(back - xy).max() < 0.2 and np.median(np.abs(back - xy)) < 1e-3
+
+
+def test_search_by_projection_known_answers():
+    """Hand-made scene for ORBmatcher::SearchByProjection (src/ORBmatcher.cc:46-137, :1412-1566): first-come
+    exclusion, the same-level ratio rule, the right-coordinate rule and the level window."""
+    from oracle import pyoracle as orc
+    import orbslam2_amd as orbx
+    kps = np.zeros(4, orbx.KEYPOINT_DTYPE)
+    kps["x"] = [100, 102, 300, 500]
+    kps["y"] = [100, 101, 200, 300]
+    kps["octave"] = [1, 1, 2, 0]
+    desc = np.zeros((4, 32), np.uint8)
+    desc[1, 0] = 0x0F        # 4 bits from feature 0
+    desc[2, :4] = 0xFF       # 32 bits
+    desc[3, :2] = 0xFF       # 16 bits
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    zero = np.zeros((1, 32), np.uint8)
+
+    def run(x, y, r, lo, hi, sd, **kw):
+        return orc.search_by_projection(kps, desc, bounds, np.float32(x), np.float32(y), np.float32(r), np.int32(lo),
+                                        np.int32(hi), sd, kw.pop("ratio", 0.8), **kw)
+
+    # one source over features 0 and 1 (same level): best 0 bits, second 4 bits: 0 > 0.8*4 is false -> accepted
+    nm, match, fm = run([101], [100], [5], [0], [1], zero)
+    assert nm == 1 and list(match) == [0] and list(fm) == [0, -1, -1, -1]
+    # descriptor 3 bits from feature 0 and 1 bit from feature 1: best = feature 1 (1), second = feature 0 (3),
+    # same level and 1 > 0.3*3: rejected by the ratio rule; accepted when the levels differ
+    sd = np.zeros((1, 32), np.uint8)
+    sd[0, 0] = 0x07
+    nm, match, _ = run([101], [100], [5], [0], [1], sd, ratio=0.3)
+    assert nm == 0 and list(match) == [-1]
+    kps["octave"][1] = 0
+    nm, match, _ = run([101], [100], [5], [0], [1], sd, ratio=0.3)
+    assert nm == 1 and list(match) == [1]
+    kps["octave"][1] = 1
+    # two sources aim at feature 0: the first wins it, the second falls back to feature 1 ...
+    two = np.zeros((2, 32), np.uint8)
+    nm, match, fm = run([101, 101], [100, 100], [5, 5], [0, 0], [1, 1], two, use_second=False)
+    assert nm == 2 and list(match) == [0, 1] and list(fm[:2]) == [0, 1]
+    # ... unless the first source's map point has no observations: then both write feature 0
+    nm, match, fm = run([101, 101], [100, 100], [5, 5], [0, 0], [1, 1], two, use_second=False,
+                        blocks=np.array([0, 1], np.uint8))
+    assert nm == 2 and list(match) == [0, 0] and fm[0] == 1
+    # features that already hold an observed map point are skipped
+    nm, match, _ = run([101], [100], [5], [0], [1], zero, taken=np.array([1, 0, 0, 0], np.uint8), use_second=False)
+    assert list(match) == [1]
+    # level window: feature 2 (level 2) is outside [0, 1]; distance above TH_HIGH is refused
+    nm, match, _ = run([300], [200], [5], [0], [1], zero)
+    assert nm == 0
+    nm, match, _ = run([300], [200], [5], [1], [2], zero, th_dist=31)
+    assert nm == 0
+    nm, match, _ = run([300], [200], [5], [1], [2], zero, th_dist=32)
+    assert list(match) == [2]
+    # right-coordinate rule: |xr - uright| > r drops the candidate, uright <= 0 (no stereo match) does not
+    ur = np.array([-1, -1, -1, 480], np.float32)
+    nm, match, _ = run([500], [300], [5], [0], [0], zero, uright=ur, xr=np.array([486], np.float32))
+    assert nm == 0
+    nm, match, _ = run([500], [300], [5], [0], [0], zero, uright=ur, xr=np.array([484], np.float32))
+    assert list(match) == [3]
