@@ -31,4 +31,5 @@ timeout -k 10 300 python3 tools/stereo_rate.py > "$OUT/stereo_rate.json" 2>/dev/
 timeout -k 10 300 python3 tools/distinctive_rate.py > "$OUT/distinctive_rate.json" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/bow_rate.py > "$OUT/bow_rate.json" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/voc_rate.py > "$OUT/voc_rate.json" 2>/dev/null || exit 1
+timeout -k 10 300 python3 tools/projection_rate.py > "$OUT/projection_rate.json" 2>/dev/null || exit 1
 echo collected
