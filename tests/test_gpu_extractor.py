@@ -336,3 +336,38 @@ def test_batch_download_all_equals_per_frame(oracle):
     ko, do = oracle_extract(oracle, imgs[7], TUM)
     compare_frame(both[7][0], both[7][1], ko, do)
     assert len(both[4][0]) == 0
+
+
+def _texture_images(w, h):
+    """Image statistics the rectangle generator does not produce: a checkerboard (hundreds of corners with
+    equal responses, so the quadtree's keep-best and its last-round ordering work on ties), a low-pass
+    random field (soft, blob-like corners, many near the thresholds), text-like bars with saturated
+    pixels, and a steep ramp with salt noise (isolated maxima)."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    board = (((xx // 23) + (yy // 19)) % 2 * 170 + 40).astype(np.uint8)
+    rng = np.random.default_rng(99)
+    field = rng.normal(0, 1, (h // 4 + 2, w // 4 + 2))
+    field = np.kron(field, np.ones((4, 4)))[:h, :w]
+    for _ in range(3):
+        field = (field + np.roll(field, 1, 0) + np.roll(field, -1, 0) + np.roll(field, 1, 1) + np.roll(field, -1, 1)) / 5
+    field = np.clip(128 + field * 220, 0, 255).astype(np.uint8)
+    bars = np.full((h, w), 255, np.uint8)
+    bars[(yy % 37 < 9) & (xx % 11 < 4)] = 0
+    bars[(yy % 53 < 3)] = 0
+    ramp = np.clip((xx * 255 // max(w - 1, 1)) + (rng.random((h, w)) < 0.002) * 90, 0, 255).astype(np.uint8)
+    return {"board": board, "field": field, "bars": bars, "ramp": ramp}
+
+
+@pytest.mark.parametrize("kind", ["board", "field", "bars", "ramp"])
+def test_other_image_statistics(oracle, kind):
+    w, h = 752, 480
+    img = _texture_images(w, h)[kind]
+    ex = make_extractor(EUROC_STEREO, w, h)
+    kg, dg = ex(img)
+    ko, do, tr = oracle_extract(oracle, img, EUROC_STEREO, trace=True)
+    _, per_level = ex.batch_counts()
+    assert list(per_level[0]) == tr["nkeep"]
+    compare_frame(kg, dg, ko, do)
+    if kind in ("board", "field", "bars"):
+        assert len(kg) > 300
+    ex.close()
