@@ -50,6 +50,10 @@ struct orbx_extractor {
     uint8_t *h_stage;              // pinned staging for host frames (level-0 layout), allocated on first use
     size_t h_stage_bytes;
     hipEvent_t ev_staged;          // the uploads out of h_stage have finished
+    uint8_t *d_stage;              // device copy of page-locked host frames in their own layout
+    size_t d_stage_bytes;
+    uint8_t *h_out;                // pinned staging of whole-batch downloads into pageable memory
+    size_t h_out_bytes;
     float sf[ORBX_MAX_LEVELS], inv[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], invsig2[ORBX_MAX_LEVELS];
     int quota[ORBX_MAX_LEVELS];
     OrbxGeom cap_geom;  // geometry of max_width x max_height: sizes every buffer
@@ -331,6 +335,10 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->ev_pyramid = ex->ev_blur = ex->ev_staged = nullptr;
     ex->h_stage = nullptr;
     ex->h_stage_bytes = 0;
+    ex->d_stage = nullptr;
+    ex->d_stage_bytes = 0;
+    ex->h_out = nullptr;
+    ex->h_out_bytes = 0;
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
@@ -416,6 +424,8 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *ex)
     if (ex->ev_blur) (void)hipEventDestroy(ex->ev_blur);
     if (ex->ev_staged) (void)hipEventDestroy(ex->ev_staged);
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
+    if (ex->d_stage) (void)hipFree(ex->d_stage);
+    if (ex->h_out) (void)hipHostFree(ex->h_out);
     if (ex->aux_stream) (void)hipStreamDestroy(ex->aux_stream);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     delete ex;
@@ -570,6 +580,42 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
     if (rc != ORBX_OK)
         return rc;
     const OrbxLevel &L0 = ex->geom.lv[0];
+    for (int f = 0; f < batch; f++)
+        if (!images[f])
+            return ORBX_E_ARG;
+    // Frames in page-locked host memory (hipHostMalloc, hipHostRegister, a pinned torch tensor) are read
+    // by the copy engine where they lie: no staging pass over them on the CPU.
+    bool pinned = true;
+    for (int f = 0; f < batch && pinned; f++) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, images[f]) != hipSuccess) {
+            (void)hipGetLastError();  // an ordinary pageable pointer is reported as an error: clear it
+            pinned = false;
+        } else
+            pinned = attr.type == hipMemoryTypeHost;
+    }
+    if (pinned) {
+        // one contiguous copy per frame in the frame's own row layout (strided copies are slow even from
+        // page-locked memory), then the device path: read in place when rows are word aligned, else
+        // repacked by the ingest kernel
+        const size_t src_bytes = (size_t)stride_bytes * (height - 1) + width;
+        const size_t fstride = (src_bytes + 255) / 256 * 256;
+        const size_t need = fstride * (size_t)batch;
+        if (ex->d_stage_bytes < need) {
+            HIP_TRY(hipStreamSynchronize(ex->stream));
+            HIP_TRY(hipStreamSynchronize(ex->aux_stream));
+            if (ex->d_stage)
+                HIP_TRY(hipFree(ex->d_stage));
+            ex->d_stage = nullptr;
+            ex->d_stage_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&ex->d_stage, need + 256));
+            ex->d_stage_bytes = need;
+        }
+        for (int f = 0; f < batch; f++)
+            HIP_TRY(hipMemcpyAsync(ex->d_stage + (size_t)f * fstride, images[f], src_bytes, hipMemcpyHostToDevice,
+                                   ex->stream));
+        return orbx_extract_batch_device(ex, ex->d_stage, batch, width, height, stride_bytes, (int64_t)fstride);
+    }
     // Pageable rows go through a pinned staging buffer in the level-0 layout: one contiguous
     // asynchronous copy per frame (a strided copy out of pageable memory costs milliseconds).
     const size_t frame_bytes = (size_t)L0.pitch * L0.h;
@@ -585,9 +631,6 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
     } else {
         HIP_TRY(hipEventSynchronize(ex->ev_staged));  // the previous batch has left the staging buffer
     }
-    for (int f = 0; f < batch; f++)
-        if (!images[f])
-            return ORBX_E_ARG;
     HIP_TRY(prof_mark(ex, 0, 0, ex->stream));
     // rows into the staging buffer: on the calling thread for a few frames, else on up to four threads,
     // each followed by the asynchronous copies of its frames (in frame order on the one stream)
@@ -720,13 +763,65 @@ extern "C" int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *keypoi
     int status[ORBX_ST_COUNT];
     HIP_TRY(hipMemcpyAsync(counts, ex->buf.out_n, sizeof(int) * B, hipMemcpyDeviceToHost, ex->stream));
     HIP_TRY(hipMemcpyAsync(status, ex->buf.status, sizeof(status), hipMemcpyDeviceToHost, ex->stream));
-    // frame f of the device arrays starts at f * out_cap entries; the caller's at f * cap_per_frame
-    HIP_TRY(hipMemcpy2DAsync(keypoints, (size_t)cap_per_frame * sizeof(orbx_keypoint), ex->buf.out_kp,
-                             (size_t)oc * sizeof(orbx_keypoint), (size_t)oc * sizeof(orbx_keypoint), B,
-                             hipMemcpyDeviceToHost, ex->stream));
-    HIP_TRY(hipMemcpy2DAsync(descriptors, (size_t)cap_per_frame * 32, ex->buf.out_desc, (size_t)oc * 32,
-                             (size_t)oc * 32, B, hipMemcpyDeviceToHost, ex->stream));
-    HIP_TRY(hipStreamSynchronize(ex->stream));
+    // frame f of the device arrays starts at f * out_cap entries; the caller's at f * cap_per_frame.
+    // Page-locked destinations are written by the copy engine; pageable ones are filled from a pinned
+    // staging buffer on four threads (a direct copy into pageable memory runs at a few GB/s).
+    const size_t kp_row = (size_t)oc * sizeof(orbx_keypoint), de_row = (size_t)oc * 32;
+    auto is_pinned = [](const void *p) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return attr.type == hipMemoryTypeHost;
+    };
+    if (is_pinned(keypoints) && is_pinned(descriptors)) {
+        if (cap_per_frame == oc) {
+            HIP_TRY(hipMemcpyAsync(keypoints, ex->buf.out_kp, kp_row * B, hipMemcpyDeviceToHost, ex->stream));
+            HIP_TRY(hipMemcpyAsync(descriptors, ex->buf.out_desc, de_row * B, hipMemcpyDeviceToHost, ex->stream));
+        } else {
+            for (int f = 0; f < B; f++) {
+                HIP_TRY(hipMemcpyAsync(keypoints + (size_t)f * cap_per_frame, ex->buf.out_kp + (size_t)f * oc, kp_row,
+                                       hipMemcpyDeviceToHost, ex->stream));
+                HIP_TRY(hipMemcpyAsync(descriptors + (size_t)f * cap_per_frame * 32, ex->buf.out_desc + (size_t)f * de_row,
+                                       de_row, hipMemcpyDeviceToHost, ex->stream));
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(ex->stream));
+    } else {
+        const size_t need = (kp_row + de_row) * (size_t)ex->p.max_batch;
+        if (ex->h_out_bytes < need) {
+            if (ex->h_out)
+                HIP_TRY(hipHostFree(ex->h_out));
+            ex->h_out = nullptr;
+            ex->h_out_bytes = 0;
+            HIP_TRY(hipHostMalloc((void **)&ex->h_out, need, hipHostMallocDefault));
+            ex->h_out_bytes = need;
+        }
+        uint8_t *h_kp = ex->h_out, *h_de = ex->h_out + kp_row * B;
+        HIP_TRY(hipMemcpyAsync(h_kp, ex->buf.out_kp, kp_row * B, hipMemcpyDeviceToHost, ex->stream));
+        HIP_TRY(hipMemcpyAsync(h_de, ex->buf.out_desc, de_row * B, hipMemcpyDeviceToHost, ex->stream));
+        HIP_TRY(hipStreamSynchronize(ex->stream));
+        // only the rows that hold results
+        auto unload = [&](int f) {
+            const size_t n = (size_t)std::min(std::max(counts[f], 0), oc);
+            memcpy(keypoints + (size_t)f * cap_per_frame, h_kp + (size_t)f * kp_row, n * sizeof(orbx_keypoint));
+            memcpy(descriptors + (size_t)f * cap_per_frame * 32, h_de + (size_t)f * de_row, n * 32);
+        };
+        const int nthreads = B >= 8 ? 4 : 1;
+        if (nthreads > 1) {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; t++)
+                pool.emplace_back([&, t]() {
+                    for (int f = t; f < B; f += nthreads)
+                        unload(f);
+                });
+            for (auto &th : pool)
+                th.join();
+        } else
+            for (int f = 0; f < B; f++)
+                unload(f);
+    }
     if (status[ORBX_ST_CAND_OVERFLOW] || status[ORBX_ST_NODE_OVERFLOW])
         return ORBX_E_CAPACITY;
     return ORBX_OK;

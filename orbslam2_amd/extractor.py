@@ -140,8 +140,8 @@ class ORBextractor:
         """Keypoints and descriptors of every frame of the last batch with one synchronisation:
         returns a list of (keypoints, descriptors) per frame."""
         b, cap = self._last[0], self.max_keypoints
-        kps = np.zeros((b, cap), L.KEYPOINT_DTYPE)
-        desc = np.zeros((b, cap, 32), np.uint8)
+        kps = np.empty((b, cap), L.KEYPOINT_DTYPE)   # rows behind a frame's count are not written
+        desc = np.empty((b, cap, 32), np.uint8)
         n = np.zeros(b, np.int32)
         L.check(self._lib.orbx_batch_download_all(self._h, L.ptr(kps), L.ptr(desc), cap, L.ptr(n)),
                 "orbx_batch_download_all")
