@@ -315,29 +315,30 @@ hipError_t orbx_launch_voc_transform(const uint8_t *d_node_desc, const int *d_ch
 
 // ---- brute-force top-2 on the matrix cores ----
 // With bits mapped to +-1, the dot product of two 256-bit descriptors is 256 - 2 * distance, so the
-// distances of 32 database rows against 32 queries are one 32x32x256 integer matrix product: eight
-// v_mfma_i32_32x32x32_i8.  Both operands carry +-64 (0x40 / 0xc0: one differing bit, which keeps the
-// switching activity and with it the clock drop of the matrix cores low: random +-127 operands run 17 %
-// slower), so a result is 4096 * dot with room below it (dots differ by at least 2, i.e. 8192) for a row code that the
-// accumulator input adds for free: results come out of the matrix core as sortable keys
-//     key = 4096 * dot + rowcode,   rowcode = 31 - (row inside the tile) + 32 * (tiles processed since),
-// larger key = smaller distance, and among equal distances the earlier row.  Every lane holds one query
-// (the column) and 16 rows of a tile, so the top-2 bookkeeping is a max and a median-of-three per
-// result; before a new tile the two running keys move up by 32, which keeps earlier rows ahead.
-// A workgroup expands each tile of database rows from bits to bytes once, into LDS in operand order,
-// for its four waves (128 queries each, held as operands in registers for the whole sweep).
+// distances of 32 database rows against 32 queries are one 32x32x256 matrix product.  CDNA4's fastest
+// exact format for it is FP4 (E2M1: +1 = 0x2, -1 = 0xa): four v_mfma_scale_f32_32x32x64_f8f6f4, 1.74 times
+// the rate of the i8 products (tools/probe_mfma_f4.hip, tools/ubench_mfma_i8.hip).  Products and sums
+// are small integers, exact in the f32 accumulators.  The block scales (2^7 on either side) multiply
+// every product by 16384, which leaves room below a result (dots differ by at least 2, i.e. 32768) for a
+// row code that the accumulator input adds for free: results leave the matrix core as sortable keys
+//     key = 16384 * (dot + 256) + rowcode,   rowcode = 31 - (row inside the tile) + 32 * (tiles since),
+// larger key = smaller distance, and among equal distances the earlier row.  Keys are non-negative
+// floats below 2^24, so their bit patterns order like integers and the bookkeeping runs on v_max3_i32 /
+// v_med3_i32; before a new tile the two running keys move up by 32 (one float addition), which keeps
+// earlier rows ahead.  Every lane holds one query (the column) and 16 rows of a tile.
+// A workgroup expands each tile of database rows from bits to FP4 once, into LDS in operand order, for
+// its four waves (32 * QT queries each, held as operands in registers for the whole sweep).
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
-#define MF_DB_C 64      // database bytes are +-64
-#define MF_Q_C 64       // query bytes are +-64
-#define MF_UNIT (MF_DB_C * MF_Q_C)        // 4096: key step per unit of dot
-#define MF_STEP (2 * MF_UNIT)             // 8192: key step between neighbouring distances
-#define MF_OFFS (MF_UNIT * 256)           // key + MF_OFFS = MF_STEP * (256 - distance) + rowcode
-#define MF_NONE (-(1 << 30))              // running key of "no row yet"
-#define MF_INVALID (-(1 << 29))           // accumulator input of rows behind the end of the database
-#define MF_MAX_CHUNK 8160                 // rows per chunk: the row code must stay below MF_STEP
-#define MF_QT 4                           // 32-query tiles per wave
+#define MF_SCALE 134                      // E8M0 block scale of both operands: 2^(134-127) = 128
+#define MF_UNIT 16384                     // 128 * 128: key step per unit of dot
+#define MF_STEP (2 * MF_UNIT)             // 32768: key step between neighbouring distances
+#define MF_BIAS ((float)(MF_UNIT * 256))  // accumulator input that makes every key non-negative
+#define MF_INVALID (-268435456.0f)        // accumulator input of rows behind the end of the database
+#define MF_MAX_CHUNK 32736                // rows per chunk: the row code must stay below MF_STEP
+#define MF_QT 8                           // 32-query tiles per wave
 #define MF_QPB (4 * 32 * MF_QT)           // queries per workgroup of four waves
 
 // median of three; written in the form the compiler selects as one v_med3_i32, so that it also places
@@ -357,17 +358,19 @@ __device__ __forceinline__ int mf_max3_after(int a, int b, int c, int after)
     return r;
 }
 
-// 16 descriptor bits -> 16 bytes of +-c (lut = byte 0: -c, byte 1: +c)
-__device__ __forceinline__ v4i mf_expand16(uint32_t bits, uint32_t lut)
+// 8 descriptor bits -> 8 FP4 values in a dword, bit i in nibble i: 1 -> 0x2 (+1.0), 0 -> 0xa (-1.0)
+__device__ __forceinline__ uint32_t mf_expand8(uint32_t b)
 {
-    v4i out;
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        const uint32_t nib = (bits >> (4 * n)) & 0xfu;
-        const uint32_t sel = __umul24(nib, 0x00204081u) & 0x01010101u;  // bit i of the nibble -> byte i
-        out[n] = (int)__builtin_amdgcn_perm(0u, lut, sel);
-    }
-    return out;
+    uint32_t x = (b | (b << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return 0xaaaaaaaau ^ (x << 3);
+}
+
+// the 128-bit FP4 operand as the 256-bit value the builtin takes (an FP4 operand occupies four registers)
+__device__ __forceinline__ v8i mf_operand(const v4i &x)
+{
+    return v8i{x[0], x[1], x[2], x[3], 0, 0, 0, 0};
 }
 
 template <int QT>  // 32-query tiles per wave
@@ -375,22 +378,24 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
                                                    const uint32_t *__restrict__ db, long long ndb, int chunk_rows,
                                                    uint2 *__restrict__ partial)
 {
-    __shared__ __attribute__((aligned(16))) v4i tile[2][8 * 64];  // [buffer][step * 64 + operand lane]
-    __shared__ uint2 lut8[256];                                   // 8 bits -> 8 bytes of +-MF_DB_C
+    __shared__ __attribute__((aligned(16))) v4i tile[2][4 * 64];  // [buffer][k-step * 64 + operand lane]
+    __shared__ uint32_t lut8[256];                                // 8 bits -> 8 FP4 values
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, half = lane >> 5;
-    const uint32_t lut_q = ((uint32_t)(-MF_Q_C) & 0xffu) | ((uint32_t)MF_Q_C << 8);
-    const uint32_t lut_d = ((uint32_t)(-MF_DB_C) & 0xffu) | ((uint32_t)MF_DB_C << 8);
-    // the wave's QT x 32 queries as B operands of the 8 k-steps
+    // Operand layout of the 32x32x64 product (tools/probe_mfma_f4.hip): lane = (row or column lane & 31,
+    // k-half lane >> 5); the lane's 32 values of k sit in nibbles 0..31 of its four registers.  K-step s
+    // covers descriptor bits 64 s .. 64 s + 63, so a lane's operand is dword 2 s + half of the descriptor.
     const int qbase = (blockIdx.x * 4 + wv) * (32 * QT);
-    v4i bq[QT][8];
+    v4i bq[QT][4];
 #pragma unroll
     for (int t = 0; t < QT; t++) {
         const int qi = qbase + 32 * t + col;
 #pragma unroll
-        for (int s = 0; s < 8; s++) {
-            const uint32_t w = qi < nq ? q[(size_t)qi * 8 + s] : 0u;
-            bq[t][s] = mf_expand16((w >> (16 * half)) & 0xffffu, lut_q);
+        for (int s = 0; s < 4; s++) {
+            const uint32_t w = qi < nq ? q[(size_t)qi * 8 + 2 * s + half] : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                bq[t][s][j] = (int)mf_expand8((w >> (8 * j)) & 0xffu);
         }
     }
     const bool wave_active = qbase < nq;
@@ -398,26 +403,23 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
     const int rows = (int)min((long long)chunk_rows, ndb - row0);
     const int ntiles = (rows + 31) / 32;
     // accumulator input of a tile: register reg of this lane is row (reg&3) + 8*(reg>>2) + 4*half
-    v16i cfull;
+    v16f cfull;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++)
-        cfull[reg] = 31 - ((reg & 3) + 8 * (reg >> 2) + 4 * half);
-    int k1[QT], k2[QT];
+        cfull[reg] = MF_BIAS + (float)(31 - ((reg & 3) + 8 * (reg >> 2) + 4 * half));
+    int k1[QT], k2[QT];  // bit patterns of the two running keys; 0 = no row yet
 #pragma unroll
     for (int t = 0; t < QT; t++)
-        k1[t] = k2[t] = MF_NONE;
+        k1[t] = k2[t] = 0;
 
     // expansion of one tile of database rows: thread = (row tid & 31, dword tid >> 5), eight bits at a
-    // time through a 256-entry table of 8-byte groups.  While tile t is multiplied, tile t+2 is expanded
-    // into the buffer tile t came from and its dword for tile t+3 is requested, and the operands of
-    // tile t+1 are read behind the last products that use those of tile t: no step waits for memory.
-    {
-        const uint32_t lo = __umul24((uint32_t)tid & 0xfu, 0x00204081u) & 0x01010101u;
-        const uint32_t hi = __umul24((uint32_t)tid >> 4, 0x00204081u) & 0x01010101u;
-        lut8[tid] = make_uint2(__builtin_amdgcn_perm(0u, lut_d, lo), __builtin_amdgcn_perm(0u, lut_d, hi));
-    }
+    // time through a 256-entry table.  While tile t is multiplied, tile t+2 is expanded into the buffer
+    // tile t came from and its dword for tile t+3 is requested, and the operands of tile t+1 are read
+    // behind the last products that use those of tile t: no step waits for memory.
+    lut8[tid] = mf_expand8((uint32_t)tid);
     __syncthreads();
     const int xr = tid & 31, xs = tid >> 5;
+    const int xslot = (xs >> 1) * 64 + (xs & 1) * 32 + xr;  // k-step, k-half, row
     // byte offset of this thread's dword of tile t inside the chunk; rows behind the end of the chunk
     // read its last row: whatever they hold never wins (MF_INVALID)
     const char *chunk = reinterpret_cast<const char *>(db + (size_t)row0 * 8);
@@ -427,46 +429,46 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
         return *reinterpret_cast<const uint32_t *>(chunk + off);
     };
     auto expand_word = [&](uint32_t w, int buf) {
-        const uint2 e0 = lut8[w & 0xffu], e1 = lut8[(w >> 8) & 0xffu];
-        const uint2 e2 = lut8[(w >> 16) & 0xffu], e3 = lut8[w >> 24];
-        v4i lo4, hi4;
-        lo4[0] = (int)e0.x, lo4[1] = (int)e0.y, lo4[2] = (int)e1.x, lo4[3] = (int)e1.y;
-        hi4[0] = (int)e2.x, hi4[1] = (int)e2.y, hi4[2] = (int)e3.x, hi4[3] = (int)e3.y;
-        tile[buf][xs * 64 + xr] = lo4;
-        tile[buf][xs * 64 + 32 + xr] = hi4;
+        v4i x;
+        x[0] = (int)lut8[w & 0xffu], x[1] = (int)lut8[(w >> 8) & 0xffu];
+        x[2] = (int)lut8[(w >> 16) & 0xffu], x[3] = (int)lut8[w >> 24];
+        tile[buf][xslot] = x;
     };
     expand_word(load_word(0), 0);
     expand_word(load_word(1), 1);
     uint32_t w_next = load_word(2);
     __syncthreads();
-    v4i a[8];
+    v4i a[4];
 #pragma unroll
-    for (int s = 0; s < 8; s++)
+    for (int s = 0; s < 4; s++)
         a[s] = tile[0][s * 64 + lane];
     __syncthreads();  // buffer 0 is rewritten in the first step
 
-    // One tile against the wave's QT x 32 queries as one basic block of 8 * QT slots, one product each,
+    // One tile against the wave's QT x 32 queries as one basic block of 4 * QT slots, one product each,
     // in exactly this order of issue (nothing moves across a slot's end).  Beside the products of
     // query tile u the vector ALU folds the results of the query tile before into the running top-2
     // (those of the last one in the next step), the database tile after next is expanded (table reads
-    // behind the first products, writes one query tile later, the request for the dword of the tile
+    // behind the first products, the write one query tile later, the request for the dword of the tile
     // after that in the third), and each operand of the next database tile is read behind the last
-    // product that uses the register it lands in.  cin is the accumulator input (row codes;
+    // product that uses the register it lands in.  cin is the accumulator input (bias and row codes;
     // MF_INVALID behind the end).
     // The fold takes 16 results two at a time: with x the running maximum, the second largest of
     // everything seen is the largest of the medians med3(x, a, b) and the old second (which never
     // exceeds x): 20 operations for 16 results.  Earlier rows stay ahead at equal distance because
     // the running keys move up by one tile of row codes first.
-    v16i pend;
+    v16f pend;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++)
-        pend[reg] = MF_NONE;
+        pend[reg] = 0.f;
     int fx = 0, fy = 0, fm = 0;
-    auto fold_piece = [&](int i, int u, const v16i &r) {
-        if (i == 0)
-            fx = k1[u] + 32, fy = k2[u] + 32;
-        const int m = mf_med3(fx, r[2 * i], r[2 * i + 1]);
-        fx = mf_max3_after(fx, r[2 * i], r[2 * i + 1], m);
+    auto fold_piece = [&](int i, int u, const v16f &r) {
+        if (i == 0) {
+            fx = __float_as_int(__int_as_float(k1[u]) + 32.f);
+            fy = __float_as_int(__int_as_float(k2[u]) + 32.f);
+        }
+        const int ra = __float_as_int(r[2 * i]), rb = __float_as_int(r[2 * i + 1]);
+        const int m = mf_med3(fx, ra, rb);
+        fx = mf_max3_after(fx, ra, rb, m);
         if (i & 1)
             fy = max(max(fy, fm), m);
         else
@@ -474,37 +476,30 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
         if (i == 7)
             k1[u] = fx, k2[u] = fy;
     };
-    auto step = [&](int t, const v16i &cin) {
+    auto step = [&](int t, const v16f &cin) {
         const int buf = t & 1;
-        v16i acc[QT];
-        uint2 e0, e1, e2, e3;
+        v16f acc[QT];
+        uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
 #pragma unroll
         for (int u = 0; u < QT; u++) {
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
-                acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bq[u][s], s ? acc[u] : cin, 0, 0, 0);
+            for (int s = 0; s < 4; s++) {
+                acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mf_operand(a[s]), mf_operand(bq[u][s]),
+                                                                         s ? acc[u] : cin, 4, 4, 0, MF_SCALE, 0, MF_SCALE);
                 // results are read one slot after the product that wrote them: no wait for the matrix pipeline
 #pragma unroll
-                for (int i = s - 1; i >= 0 && i <= (s == 7 ? 7 : s - 1); i++) {
+                for (int i = (s == 0 ? 8 : 3 * (s - 1)); i < (s == 3 ? 8 : 3 * s); i++) {
                     if (u == 0)
                         fold_piece(i, QT - 1, pend);
                     else
                         fold_piece(i, u - 1, acc[u - 1]);
                 }
-                if (u == 0 && s == 1)
+                if (u == 0 && s == 1) {
                     e0 = lut8[w_next & 0xffu], e1 = lut8[(w_next >> 8) & 0xffu];
-                if (u == 0 && s == 2)
                     e2 = lut8[(w_next >> 16) & 0xffu], e3 = lut8[w_next >> 24];
-                if (u == 1 && s == 1) {
-                    v4i lo4;
-                    lo4[0] = (int)e0.x, lo4[1] = (int)e0.y, lo4[2] = (int)e1.x, lo4[3] = (int)e1.y;
-                    tile[buf][xs * 64 + xr] = lo4;
                 }
-                if (u == 1 && s == 2) {
-                    v4i hi4;
-                    hi4[0] = (int)e2.x, hi4[1] = (int)e2.y, hi4[2] = (int)e3.x, hi4[3] = (int)e3.y;
-                    tile[buf][xs * 64 + 32 + xr] = hi4;
-                }
+                if (u == 1 && s == 1)
+                    tile[buf][xslot] = v4i{(int)e0, (int)e1, (int)e2, (int)e3};
                 if (u == 2 && s == 0)
                     w_next = load_word(t + 3);
                 if (u == QT - 1)
@@ -527,8 +522,8 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
         step(nfull, cfull);
     }
 #pragma unroll
-    for (int s = 0; s < 8; s++)
-        fold_piece(s, QT - 1, pend);
+    for (int i = 0; i < 8; i++)
+        fold_piece(i, QT - 1, pend);
     if (!wave_active)
         return;
     // the two lanes of a query (rows 4*half + ...) merge; keys of different rows are distinct
@@ -539,11 +534,11 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
         const int second = max(lo, max(k2[t], o2));
         const int qi = qbase + 32 * t + col;
         if (half == 0 && qi < nq) {
-            // key + MF_OFFS = MF_STEP * (256 - distance) + rowcode; row = 32*(ntiles-1) + 31 - rowcode
-            auto decode = [&](int key) -> uint32_t {
-                if (key < -MF_OFFS + MF_STEP)  // distance 256 (never a best match) or no row at all
+            // key = MF_STEP * (256 - distance) + rowcode; row = 32*(ntiles-1) + 31 - rowcode
+            auto decode = [&](int bits) -> uint32_t {
+                if (bits < __float_as_int((float)MF_STEP))  // distance 256 (never a best match), no row, or invalid
                     return TOP2_INIT;
-                const uint32_t v = (uint32_t)(key + MF_OFFS);
+                const uint32_t v = (uint32_t)__int_as_float(bits);
                 const uint32_t u = v / MF_STEP, rc = v - u * MF_STEP;
                 return ((256u - u) << 16) | (uint32_t)(32 * (ntiles - 1) + 31 - (int)rc);
             };
