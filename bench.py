@@ -37,11 +37,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 VALU_LANE_OPS_PER_S = 256 * 64 * 2.4e9
 VALU_LANE_OPS_MEASURED = 36.0e12
 OPS_PER_PAIR = 16
-# The top-2 kernel runs on the matrix cores for 32 or more queries: a pair is 256 int8 multiply-adds of
-# v_mfma_i32_32x32x32_i8 (32 cycles per instruction and SIMD: 1024 MAC per clock and SIMD, 1024 SIMDs, 2.4 GHz);
-# tools/ubench_mfma_i8.hip sustains 2.12e15 MAC/s with random +-64 operands in registers (1.8e15 with +-127)
-MFMA_I8_MAC_PER_S = 1024 * 1024 * 2.4e9
-MFMA_I8_MAC_MEASURED = 2.124e15
+# The top-2 kernel runs on the matrix cores for 32 or more queries: a pair is 256 FP4 multiply-adds of
+# v_mfma_scale_f32_32x32x64_f8f6f4 (dense FP4 peak: twice the fp8 rate = 2048 MAC per clock and SIMD, 1024 SIMDs,
+# 2.4 GHz); tools/probe_mfma_f4.hip sustains 3.74e15 MAC/s with random +-1 operands in registers
+# (the i8 products the kernel used before: peak 2.5e15, 2.12e15 sustained, tools/ubench_mfma_i8.hip)
+MFMA_F4_MAC_PER_S = 2048 * 1024 * 2.4e9
+MFMA_F4_MAC_MEASURED = 3.737e15
 MAC_PER_PAIR = 256
 
 WORKLOADS = {
@@ -339,10 +340,10 @@ def bench_hamming(orbx, torch, stream):
     return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
             "accepted_matches": accepted, "ratio": 0.75, "th": 50, "self_check": bool(ok),
             "self_check_what": "40 of the queries against a numpy single pass over all rows (index, d1, d2)",
-            "roofline": {"bound": "mfma", "dtype": "i8", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12, 1),
-                         "peak": round(MFMA_I8_MAC_PER_S * 2 / 1e12, 1), "unit": "TOP/s",
-                         "frac": round(rate * MAC_PER_PAIR / MFMA_I8_MAC_PER_S, 4),
-                         "frac_of_measured_mfma_rate": round(rate * MAC_PER_PAIR / MFMA_I8_MAC_MEASURED, 4),
+            "roofline": {"bound": "mfma", "dtype": "fp4", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12, 1),
+                         "peak": round(MFMA_F4_MAC_PER_S * 2 / 1e12, 1), "unit": "TFLOP/s",
+                         "frac": round(rate * MAC_PER_PAIR / MFMA_F4_MAC_PER_S, 4),
+                         "frac_of_measured_mfma_rate": round(rate * MAC_PER_PAIR / MFMA_F4_MAC_MEASURED, 4),
                          "vs_valu_popcount_roofline": round(rate / peak_pairs, 4)}}
 
 
@@ -387,9 +388,9 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
     rate = nq * ndb / sec
     return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
             "shards": world, "exchange": "all_gather of 12 B per query and rank, host merge", "self_check": ok,
-            "roofline": {"bound": "mfma", "dtype": "i8", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12 / world, 1),
-                         "peak": round(MFMA_I8_MAC_PER_S * 2 / 1e12, 1), "unit": "TOP/s per GPU",
-                         "frac": round(rate / world * MAC_PER_PAIR / MFMA_I8_MAC_PER_S, 4)}}
+            "roofline": {"bound": "mfma", "dtype": "fp4", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12 / world, 1),
+                         "peak": round(MFMA_F4_MAC_PER_S * 2 / 1e12, 1), "unit": "TFLOP/s per GPU",
+                         "frac": round(rate / world * MAC_PER_PAIR / MFMA_F4_MAC_PER_S, 4)}}
 
 
 def cpu_baseline(host_frames, w, nfeat, budget_s):
