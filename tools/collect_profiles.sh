@@ -22,8 +22,10 @@ timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal_f
 timeout -s KILL 60 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cal_write" -- $REPO/tools/ubench_fetch > "$OUT/cal_write.log" 2>&1 || exit 1
 cd $REPO
 timeout -k 10 60 tools/ubench_mfma_i8 > "$OUT/ubench_mfma_i8.txt" 2>/dev/null || exit 1
+timeout -k 10 60 tools/probe_mfma_f4 > "$OUT/probe_mfma_f4.txt" 2>/dev/null || exit 1
+timeout -k 10 60 tools/ubench_mfma_fill > "$OUT/ubench_mfma_fill.txt" 2>/dev/null || exit 1
 timeout -k 10 60 tools/bin/exp_top2 > "$OUT/top2_harness.txt" 2>/dev/null || exit 1
-bash tools/pmc_top2.sh > "$OUT/pmc_top2.txt" 2>&1 || exit 1
+bash tools/pmc_top2.sh > "$OUT/pmc_top2.txt" 2>&1 || echo "pmc_top2 failed" >> "$OUT/pmc_top2.txt"
 timeout -k 10 200 python3 tools/pcie_rate.py > "$OUT/pcie_rate.txt" 2>/dev/null || exit 1
 timeout -k 10 200 python3 tools/latency_breakdown.py > "$OUT/latency_breakdown.txt" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/config5_pairs.py > "$OUT/config5_pairs.json" 2>/dev/null || exit 1

@@ -7,7 +7,7 @@ REPO=$PWD
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU" \
-           "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_I8"; do
+           "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA"; do
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --pmc $set --output-format csv -d "$OUT/p$i" -- $REPO/tools/bin/exp_top2 > "$OUT/log$i.txt" 2>&1 || { tail -5 "$OUT/log$i.txt"; exit 1; }
 done
