@@ -547,10 +547,10 @@ __global__ __launch_bounds__(256, 2) void k_top2_mfma(const uint32_t *__restrict
     }
 }
 
-// rows per chunk of the matrix-core kernel: whole tiles, at most MF_MAX_CHUNK, about 1024 workgroups
+// rows per chunk of the matrix-core kernel: whole tiles, at most MF_MAX_CHUNK, as many chunks as give
+// about 512 workgroups (two per CU are resident: the kernel holds 225 registers per lane)
 void orbx_top2_mfma_chunks(int nq, int64_t ndb, int *chunk_rows, int *nchunks)
 {
-    // two workgroups per CU are resident (registers); long chunks make the skip of the top-2 update effective
     const int qblocks = (nq + MF_QPB - 1) / MF_QPB;
     const char *env = getenv("ORBX_TOP2_BLOCKS");  // tuning runs only
     const int target = env ? atoi(env) : 512;

@@ -86,6 +86,28 @@ def test_top2_matrix_core_path_ties_at_tile_and_chunk_borders(oracle, ndb, nq):
     assert np.array_equal(d2, o2)
 
 
+def test_top2_matrix_core_longest_chunks(oracle, monkeypatch):
+    """Chunks of the greatest length the key layout allows (32736 rows: row codes up to 32767 below a key
+    step of 32768), forced through the tuning variable; ties everywhere, so the row codes decide."""
+    monkeypatch.setenv("ORBX_TOP2_BLOCKS", "1")
+    rng = np.random.default_rng(5)
+    ndb, nq = 32736 + 7301, 70
+    pool = orbx.synth_descriptors(9, 25)
+    db = pool[rng.integers(0, 25, size=ndb)]
+    q = pool[rng.integers(0, 25, size=nq)].copy()
+    q[::2, 3] ^= 0x10
+    m = orbx.ORBmatcher(0.75)
+    best, d1, d2 = m.match_top2(q, db)
+    ob, o1, o2 = oracle.match_top2(q, db)
+    assert np.array_equal(best, ob) and np.array_equal(d1, o1) and np.array_equal(d2, o2)
+    # the last rows of the first chunk and the first of the second
+    db2 = orbx.synth_descriptors(10, ndb)
+    q2 = db2[[32735, 32736, 32734, 0, ndb - 1]].copy()
+    q2 = np.concatenate([q2] * 8)
+    best, d1, d2 = m.match_top2(q2, db2)
+    assert list(best[:5]) == [32735, 32736, 32734, 0, ndb - 1] and (d1 == 0).all()
+
+
 def test_sharded_merge_equals_single_pass(oracle):
     db, q = make_db(50000, 500, seed=5)
     m = orbx.ORBmatcher(0.75)
