@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 {
     __shared__ int s_first[ORBX_MAX_LEVELS + 1];
     __shared__ float s_angle[DESC_SLOTS], s_ca[DESC_SLOTS], s_sa[DESC_SLOTS];
+    __shared__ int s_m01[DESC_SLOTS], s_m10[DESC_SLOTS];  // patch moments of the block's keypoints
     __shared__ uint32_t s_win[4][BLP_ROWS * BLP_WORDS];  // per wave; the smaller patch reuses it
     __shared__ uint32_t s_xy[DESC_SLOTS];                // level coordinates of the block's keypoints
     __shared__ int s_lvl[DESC_SLOTS], s_ki[DESC_SLOTS];  // their level and index into the kept arrays
@@ -378,12 +379,16 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         m10 = __ockl_wfred_add_i32(m10);
         m01 = __ockl_wfred_add_i32(m01);
         if (lane == 0)
-            s_angle[ls] = fast_atan2_deg((float)m01, (float)m10);
+            s_m01[ls] = m01, s_m10[ls] = m10;
     }
     __syncthreads();
+    // the angles of the block's keypoints, one thread each (inside the loop every lane of a wave would
+    // step through the polynomial for one keypoint)
     if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
+        const float ang = fast_atan2_deg((float)s_m01[threadIdx.x], (float)s_m10[threadIdx.x]);
+        s_angle[threadIdx.x] = ang;
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-        const float rad = __fmul_rn(s_angle[threadIdx.x], factorPI);
+        const float rad = __fmul_rn(ang, factorPI);
         s_ca[threadIdx.x] = (float)cos((double)rad);
         s_sa[threadIdx.x] = (float)sin((double)rad);
     }
@@ -416,7 +421,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         fetch_window(base + wv * 16);
     for (int i = 0; i < nmine; i++) {
         const int ls = wv * 16 + i, slot = base + ls;
-        const int ox = ox_next, x = nx, y = ny, lvl = nlvl;
+        const int ox = ox_next;
         __builtin_amdgcn_wave_barrier();  // the previous keypoint's samples are read before this overwrite
 #pragma unroll
         for (int j = 0; j < 7; j++)
@@ -441,20 +446,23 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         if (lane < 4)
             *reinterpret_cast<unsigned long long *>(out_desc + o * 32 + lane * 8) =
                 lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-        if (lane == 0) {
-            orbx_keypoint kp;
-            kp.x = (float)x, kp.y = (float)y;
-            if (lvl != 0) {
-                kp.x = __fmul_rn(kp.x, s_scale[ls]);
-                kp.y = __fmul_rn(kp.y, s_scale[ls]);
-            }
-            kp.size = s_size[ls];
-            kp.angle = s_angle[ls];
-            kp.response = s_resp[ls];
-            kp.octave = lvl;
-            kp.class_id = -1;
-            out_kp[o] = kp;
+    }
+    // the keypoint records, one thread each
+    if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
+        const int ls = threadIdx.x;
+        const uint32_t xy = s_xy[ls];
+        orbx_keypoint kp;
+        kp.x = (float)(xy & 0xffff), kp.y = (float)(xy >> 16);
+        if (s_lvl[ls] != 0) {
+            kp.x = __fmul_rn(kp.x, s_scale[ls]);
+            kp.y = __fmul_rn(kp.y, s_scale[ls]);
         }
+        kp.size = s_size[ls];
+        kp.angle = s_angle[ls];
+        kp.response = s_resp[ls];
+        kp.octave = s_lvl[ls];
+        kp.class_id = -1;
+        out_kp[(size_t)f * a.out_cap + base + ls] = kp;
     }
 }
 
