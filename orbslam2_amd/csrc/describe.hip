@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ int s_first[ORBX_MAX_LEVELS + 1];
     __shared__ float s_angle[DESC_SLOTS], s_ca[DESC_SLOTS], s_sa[DESC_SLOTS];
     __shared__ int s_m01[DESC_SLOTS], s_m10[DESC_SLOTS];  // patch moments of the block's keypoints
+    __shared__ int2 s_quad[4][16][16];                    // per wave and keypoint: the moments summed over each quad of lanes
     __shared__ uint32_t s_win[4][BLP_ROWS * BLP_WORDS];  // per wave; the smaller patch reuses it
     __shared__ uint32_t s_xy[DESC_SLOTS];                // level coordinates of the block's keypoints
     __shared__ int s_lvl[DESC_SLOTS], s_ki[DESC_SLOTS];  // their level and index into the kept arrays
@@ -375,11 +376,25 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // wave-wide sums through the data-parallel-primitive path (no LDS traffic)
-        m10 = __ockl_wfred_add_i32(m10);
-        m01 = __ockl_wfred_add_i32(m01);
-        if (lane == 0)
-            s_m01[ls] = m01, s_m10[ls] = m10;
+        // Sums over the wave: here only over the four lanes of a quad (two cross-lane additions each);
+        // the sixteen quad sums of every keypoint are added up after the loop, one lane per keypoint,
+        // instead of a full wave-wide reduction per keypoint.
+        m10 += __builtin_amdgcn_update_dpp(0, m10, 0xb1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+        m01 += __builtin_amdgcn_update_dpp(0, m01, 0xb1, 0xf, 0xf, false);
+        m10 += __builtin_amdgcn_update_dpp(0, m10, 0x4e, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+        m01 += __builtin_amdgcn_update_dpp(0, m01, 0x4e, 0xf, 0xf, false);
+        if ((lane & 3) == 0)
+            s_quad[wv][i][lane >> 2] = make_int2(m10, m01);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nmine) {
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int2 p = s_quad[wv][lane][k];
+            m10 += p.x, m01 += p.y;
+        }
+        s_m01[wv * 16 + lane] = m01, s_m10[wv * 16 + lane] = m10;
     }
     __syncthreads();
     // the angles of the block's keypoints, one thread each (inside the loop every lane of a wave would
