@@ -310,36 +310,51 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     }
     __syncthreads();
     // everything a window fetch needs comes from LDS: no global load sits in front of it
-    auto locate = [&](int slot, int &lvl, int &x, int &y, size_t &ki, int &pitch, int &off) {
-        const int ls = slot - base;
-        lvl = s_lvl[ls];
-        ki = (size_t)f * a.kp_per_frame + s_ki[ls];
-        const uint32_t xy = s_xy[ls];
-        x = xy & 0xffff, y = xy >> 16;
-        pitch = s_pitch[ls], off = s_off[ls];
-    };
     const int nmine = min(16, total - (base + wv * 16));  // keypoints of this wave (may be <= 0)
 
     // ---- IC_Angle: lanes 0..30 take columns u=-15..15 of rows v = 0,2,4.., lanes 32..62 of rows 1,3,5.. ----
     // The window of keypoint i+1 is fetched into registers while keypoint i is summed.
     uint32_t tmp[7];
     int ox_next = 0;
+    // The keypoint is the same for all lanes of the wave: its position and the level's pitch are made
+    // wave-uniform, so the window's start is a scalar address and a lane adds only row * pitch + 4 * word.
+    int pr[5], pc[5];  // this lane's (row, byte column) of the patch words it fetches
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int idx = lane + 64 * j;
+        pr[j] = idx / PAT_WORDS, pc[j] = 4 * (idx % PAT_WORDS);
+    }
     auto fetch_patch = [&](int slot) {
-        int lvl, x, y, bpitch, off;
-        size_t ki;
-        locate(slot, lvl, x, y, ki, bpitch, off);
-        const int pitch = s_upitch[slot - base];
+        const int ls = slot - base;
+        const uint32_t xy = __builtin_amdgcn_readfirstlane(s_xy[ls]);
+        const int x = xy & 0xffff, y = xy >> 16;
+        const int pitch = __builtin_amdgcn_readfirstlane(s_upitch[ls]);
+        const long long usrc = ((long long)__builtin_amdgcn_readfirstlane((int)(s_usrc[ls] >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)s_usrc[ls]);
         const int xa = (x - 15) & ~3;
         ox_next = (x - 15) - xa;
-        const uint8_t *src = pyr + s_usrc[slot - base] + (size_t)(y - 15) * pitch + xa;
+        const uint8_t *src = pyr + usrc + (long long)(y - 15) * pitch + xa;
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            const int idx = lane + 64 * j;
-            const int r = idx / PAT_WORDS, c = idx % PAT_WORDS;
-            tmp[j] = idx < PAT_ROWS * PAT_WORDS ? *reinterpret_cast<const uint32_t *>(src + (size_t)r * pitch + 4 * c)
-                                                : 0u;
-        }
+        for (int j = 0; j < 5; j++)
+            tmp[j] = lane + 64 * j < PAT_ROWS * PAT_WORDS
+                         ? *reinterpret_cast<const uint32_t *>(src + (uint32_t)(pr[j] * pitch + pc[j]))
+                         : 0u;
     };
+    // weights of the patch rows this lane sums: column u = (lane & 31) - 15, rows +-(half + 2k)
+    const int icu = min((lane & 31), 30) - 15, ichalf = lane >> 5;
+    int wu[8], wum[8], wv_[8];
+    {
+        constexpr int UM_EVEN[8] = {15, 15, 14, 14, 13, 11, 9, 6};  // half-widths of the circular patch,
+        constexpr int UM_ODD[8] = {15, 15, 14, 13, 12, 10, 8, 3};   // even and odd rows
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int vv = ichalf + 2 * k;
+            const bool in = (lane & 31) < 31 && abs(icu) <= (ichalf ? UM_ODD[k] : UM_EVEN[k]);
+            wu[k] = in ? icu : 0;
+            wum[k] = (in && vv != 0) ? icu : 0;  // row 0 is one row, not a pair
+            wv_[k] = in ? vv : 0;
+        }
+    }
     if (nmine > 0)
         fetch_patch(base + wv * 16);
     for (int i = 0; i < nmine; i++) {
@@ -353,26 +368,16 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             fetch_patch(base + ls + 1);
         __builtin_amdgcn_wave_barrier();
         int m10 = 0, m01 = 0;
-        const int u = (lane & 31) - 15;
-        const int half = lane >> 5;
-        if ((lane & 31) < 31) {
-            const uint8_t *ctr = winb + 15 * (PAT_WORDS * 4) + ox + 15 + u;
-            // half-widths of the circular patch for even and odd rows, as immediates
-            constexpr int UM_EVEN[8] = {15, 15, 14, 14, 13, 11, 9, 6};
-            constexpr int UM_ODD[8] = {15, 15, 14, 13, 12, 10, 8, 3};
+        {
+            // pixels outside the circular patch (and lanes 31, 63) enter with weight 0: no branches
+            const uint8_t *ctr = winb + 15 * (PAT_WORDS * 4) + ox + 15 + icu;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int vv = half + 2 * k;
-                const bool in = abs(u) <= (half ? UM_ODD[k] : UM_EVEN[k]);
+                const int vv = ichalf + 2 * k;
                 const int vp = ctr[vv * (PAT_WORDS * 4)], vm = ctr[-vv * (PAT_WORDS * 4)];
-                if (in) {
-                    if (vv == 0)
-                        m10 += u * vp;
-                    else {
-                        m10 += u * (vp + vm);
-                        m01 += vv * (vp - vm);
-                    }
-                }
+                m10 = __mul24(vp, wu[k]) + m10;
+                m10 = __mul24(vm, wum[k]) + m10;
+                m01 = __mul24(vp - vm, wv_[k]) + m01;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -416,21 +421,26 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const char4 p = *reinterpret_cast<const char4 *>(&c_pattern[(lane + 64 * j) * 4]);
         px0[j] = (float)p.x, py0[j] = (float)p.y, px1[j] = (float)p.z, py1[j] = (float)p.w;
     }
-    int nx = 0, ny = 0, nlvl = 0;
-    size_t nki = 0;
-    auto fetch_window = [&](int slot) {
-        int pitch, off;
-        locate(slot, nlvl, nx, ny, nki, pitch, off);
-        const int xa = (nx - 18) & ~3;
-        ox_next = (nx - 18) - xa;
-        const uint8_t *src = blur + (size_t)f * a.slab + off + (size_t)(ny - 18) * pitch + xa;
+    int br[7], bc[7];  // this lane's (row, byte column) of the window words it fetches
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
-            const int idx = lane + 64 * j;
-            const int r = idx / BLP_WORDS, c = idx % BLP_WORDS;
-            tmp[j] = idx < BLP_ROWS * BLP_WORDS ? *reinterpret_cast<const uint32_t *>(src + (size_t)r * pitch + 4 * c)
-                                                : 0u;
-        }
+    for (int j = 0; j < 7; j++) {
+        const int idx = lane + 64 * j;
+        br[j] = idx / BLP_WORDS, bc[j] = 4 * (idx % BLP_WORDS);
+    }
+    auto fetch_window = [&](int slot) {
+        const int ls = slot - base;
+        const uint32_t xy = __builtin_amdgcn_readfirstlane(s_xy[ls]);
+        const int x = xy & 0xffff, y = xy >> 16;
+        const int pitch = __builtin_amdgcn_readfirstlane(s_pitch[ls]);
+        const int off = __builtin_amdgcn_readfirstlane(s_off[ls]);
+        const int xa = (x - 18) & ~3;
+        ox_next = (x - 18) - xa;
+        const uint8_t *src = blur + (size_t)f * a.slab + off + (long long)(y - 18) * pitch + xa;
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            tmp[j] = lane + 64 * j < BLP_ROWS * BLP_WORDS
+                         ? *reinterpret_cast<const uint32_t *>(src + (uint32_t)(br[j] * pitch + bc[j]))
+                         : 0u;
     };
     if (nmine > 0)
         fetch_window(base + wv * 16);
