@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             if (i < BL_SH * (BL_SWORDS / 4)) {
                 const int r = i / (BL_SWORDS / 4), c = i % (BL_SWORDS / 4);
                 *reinterpret_cast<uint4 *>(&img[r * BL_SWORDS + 4 * c]) =
-                    *reinterpret_cast<const uint4 *>(s0 + (size_t)r * spitch + 16 * c);
+                    *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(r, spitch) + 16 * c));
             }
         }
     } else {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
                 const int r = (threadIdx.x >> 6) + 4 * k;
                 v[k] = 0;
                 if (r < BL_SH && !unused) {
-                    const uint8_t *row = src + (size_t)reflect101(ty0 - 3 + r, h) * spitch;
+                    const uint8_t *row = src + (uint32_t)__umul24(reflect101(ty0 - 3 + r, h), spitch);
                     if (whole)
                         v[k] = *reinterpret_cast<const uint32_t *>(row + o0);
                     else
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
                 acc[i] = min(acc[i], 0x00ffffffu);
             const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);  // bytes: acc0.b2, acc1.b2
             const uint32_t hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);  // upper half: acc2.b2, acc3.b2
-            *reinterpret_cast<uint32_t *>(dst + (size_t)y * pitch + x) = lo | hi;
+            *reinterpret_cast<uint32_t *>(dst + (uint32_t)(__umul24(y, pitch) + x)) = lo | hi;
         }
     }
 }

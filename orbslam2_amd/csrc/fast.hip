@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             if (i < IMG_H * (IMG_W / 16)) {
                 const int r = i / (IMG_W / 16), c = i % (IMG_W / 16);
                 *reinterpret_cast<uint4 *>(&img[r * IMG_W + 16 * c]) =
-                    *reinterpret_cast<const uint4 *>(s0 + (size_t)r * pitch + 16 * c);
+                    *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(r, pitch) + 16 * c));
             }
         }
     } else if (walker) {
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             const int y = ty0 - 4 + r;
             uint32_t v = 0;
             if (y >= 0 && y < h && x >= 0 && x < pitch)
-                v = *reinterpret_cast<const uint32_t *>(src + (size_t)y * pitch + x);
+                v = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(__umul24(y, pitch) + x));
             img32[r * IMG_WORDS + GRP_0 + g] = v;
         }
     }

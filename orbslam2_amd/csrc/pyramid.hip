@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
     const uint32_t wb = (uint32_t)sx[0] & ~3u;  // aligned byte offset of the first word
     const uint32_t s0 = (uint32_t)sx[0] & 3u;
     const uint32_t last_row = max(max(cy[0].x, cy[0].y), max(cy[1].x, cy[1].y));
-    const bool narrow = sx[3] + 1 - sx[0] <= 7 && last_row * (uint32_t)spitch + wb + 12u <= src_bytes;
+    const bool narrow = sx[3] + 1 - sx[0] <= 7 && __umul24(last_row, (uint32_t)spitch) + wb + 12u <= src_bytes;
     uint32_t h[RS_ROWS][2][4];
     if (narrow) {
         uint32_t sel[4];
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
         for (int r = 0; r < RS_ROWS; r++)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const uint32_t off = (k ? cy[r].y : cy[r].x) * (uint32_t)spitch + wb;
+                const uint32_t off = __umul24(k ? cy[r].y : cy[r].x, (uint32_t)spitch) + wb;  // rows and pitch are below 2^13
                 const uint32_t *row = reinterpret_cast<const uint32_t *>(sbase + off);
                 const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
                 const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, s0);  // source bytes sx0 .. sx0+3
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
         for (int r = 0; r < RS_ROWS; r++)
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const uint8_t *row = sbase + (size_t)(k ? cy[r].y : cy[r].x) * spitch;
+                const uint8_t *row = sbase + __umul24(k ? cy[r].y : cy[r].x, (uint32_t)spitch);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     // a1 == 0 marks columns whose right neighbour must not be read
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
             const uint32_t v = ((__umul24(cy[r].z, h[r][0][i] >> 4) >> 16) + (__umul24(cy[r].w, h[r][1][i] >> 4) >> 16) + 2u) >> 2;
             out |= v << (8 * i);
         }
-        *reinterpret_cast<uint32_t *>(dbase + (size_t)(dy0 + r) * dpitch + dx0) = out;
+        *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy0 + r, dpitch) + dx0)) = out;
     }
 }
 
