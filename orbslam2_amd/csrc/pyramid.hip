@@ -112,13 +112,23 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
     for (int r = 0; r < RS_ROWS; r++) {
         if (dy0 + r >= dh)
             break;
-        uint32_t out = 0;
+        // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 for four pixels: the upper halves of
+        // the eight products are gathered two pixels to a register and added, rounded and shifted as packed
+        // 16-bit values (both products stay below 2^27, so 24-bit multiplies are exact)
+        uint32_t p0[4], p1[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            // both products stay below 2^27: 24-bit multiplies are exact
-            const uint32_t v = ((__umul24(cy[r].z, h[r][0][i] >> 4) >> 16) + (__umul24(cy[r].w, h[r][1][i] >> 4) >> 16) + 2u) >> 2;
-            out |= v << (8 * i);
+            p0[i] = __umul24(cy[r].z, h[r][0][i] >> 4);
+            p1[i] = __umul24(cy[r].w, h[r][1][i] >> 4);
         }
+        typedef unsigned short rs_pk __attribute__((ext_vector_type(2)));
+        auto pair = [&](int i) -> uint32_t {
+            const uint32_t t = __builtin_amdgcn_perm(p0[i + 1], p0[i], 0x07060302u);  // hi16(p0[i]) | hi16(p0[i+1]) << 16
+            const uint32_t u = __builtin_amdgcn_perm(p1[i + 1], p1[i], 0x07060302u);
+            const rs_pk sum = __builtin_bit_cast(rs_pk, t) + __builtin_bit_cast(rs_pk, u) + (rs_pk){2, 2};
+            return __builtin_bit_cast(uint32_t, (rs_pk)(sum >> (rs_pk){2, 2}));
+        };
+        const uint32_t out = __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u);  // the four low bytes
         *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy0 + r, dpitch) + dx0)) = out;
     }
 }
