@@ -338,6 +338,43 @@ def test_batch_download_all_equals_per_frame(oracle):
     assert len(both[4][0]) == 0
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (333, 217)])
+def test_page_locked_frames_and_results(oracle, w, h):
+    """Frames in page-locked host memory are uploaded where they lie (one contiguous copy per frame, then
+    the device path: in place for word-aligned rows, repacked otherwise), and page-locked result arrays
+    are filled by the copy engine: both must give what the staged paths give."""
+    import ctypes as C
+    import torch
+    from orbslam2_amd import _lib as L
+    B = 9
+    imgs = [orbx.synth_image(SEED + 17 * i, w, h, 0) for i in range(B)]
+    pin = torch.empty((B, h, w), dtype=torch.uint8).pin_memory()
+    pinned = [pin[i].numpy() for i in range(B)]
+    for i in range(B):
+        pinned[i][:] = imgs[i]
+    ex = make_extractor(TUM, w, h, batch=B)
+    ex.extract_batch_host(imgs)
+    ref = ex.batch_download_all()
+    ex.extract_batch_host(pinned)
+    got = ex.batch_download_all()
+    for f in range(B):
+        assert np.array_equal(ref[f][0], got[f][0]) and np.array_equal(ref[f][1], got[f][1])
+    ko, do = oracle_extract(oracle, imgs[3], TUM)
+    compare_frame(got[3][0], got[3][1], ko, do)
+    # page-locked destination
+    cap = ex.max_keypoints
+    kp_t = torch.empty((B, cap * L.KEYPOINT_DTYPE.itemsize), dtype=torch.uint8).pin_memory()
+    de_t = torch.empty((B, cap, 32), dtype=torch.uint8).pin_memory()
+    n = np.zeros(B, np.int32)
+    L.check(L.lib().orbx_batch_download_all(ex._h, C.c_void_p(kp_t.data_ptr()), C.c_void_p(de_t.data_ptr()), cap,
+                                            L.ptr(n)), "orbx_batch_download_all")
+    kps = kp_t.numpy().view(L.KEYPOINT_DTYPE).reshape(B, cap)
+    for f in range(B):
+        assert n[f] == len(ref[f][0])
+        assert np.array_equal(kps[f, :n[f]], ref[f][0]) and np.array_equal(de_t.numpy()[f, :n[f]], ref[f][1])
+    ex.close()
+
+
 def _texture_images(w, h):
     """Image statistics the rectangle generator does not produce: a checkerboard (hundreds of corners with
     equal responses, so the quadtree's keep-best and its last-round ordering work on ties), a low-pass
