@@ -551,3 +551,34 @@ def test_search_by_projection_last_frame_vs_oracle(oracle, mode, ori):
     assert np.array_equal(match, omatch) and np.array_equal(fm, ofm)
     if ori:
         assert (fm == -2).sum() > 10        # the planted 140-degree rotations fall outside the three maxima
+
+
+def test_search_by_projection_edges(oracle):
+    """No sources, no features, and a window that holds more candidates than the kernel's lists (an error,
+    not a wrong answer)."""
+    m = orbx.ORBmatcher(0.8)
+    kps = np.zeros(300, orbx.KEYPOINT_DTYPE)
+    kps["x"] = 100 + (np.arange(300) % 20)
+    kps["y"] = 100 + (np.arange(300) // 20)
+    desc = orbx.synth_descriptors(2, 300)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    e = np.zeros(0, np.float32)
+    ei = np.zeros(0, np.int32)
+    nm, match, fm = m.search_by_projection(kps, desc, bounds, e, e, e, ei, ei, np.zeros((0, 32), np.uint8))
+    assert nm == 0 and len(match) == 0 and (fm == -1).all()
+    one = np.array([105.0], np.float32)
+    nm, match, fm = m.search_by_projection(kps[:0], desc[:0], bounds, one, one, np.array([5.0], np.float32),
+                                           np.array([0], np.int32), np.array([-1], np.int32), desc[:1])
+    assert nm == 0 and list(match) == [-1] and len(fm) == 0
+    # 300 features inside one window: the lists hold 256
+    with pytest.raises(orbx.OrbxError):
+        m.search_by_projection(kps, desc, bounds, np.array([110.0], np.float32), np.array([107.0], np.float32),
+                               np.array([60.0], np.float32), np.array([0], np.int32), np.array([-1], np.int32), desc[:1])
+    # 200 of them: the crowded-window path (more than the 32 staged candidates) agrees with the oracle
+    x, y, r = np.array([110.0], np.float32), np.array([104.5], np.float32), np.array([30.0], np.float32)
+    sub = kps[:200]
+    nm, match, fm = m.search_by_projection(sub, desc[:200], bounds, x, y, r, np.array([0], np.int32),
+                                           np.array([-1], np.int32), desc[150:151], use_second=False)
+    onm, omatch, ofm = oracle.search_by_projection(sub, desc[:200], bounds, x, y, r, np.array([0], np.int32),
+                                                   np.array([-1], np.int32), desc[150:151], 0.8, use_second=False)
+    assert nm == onm == 1 and list(match) == list(omatch) == [150] and np.array_equal(fm, ofm)
