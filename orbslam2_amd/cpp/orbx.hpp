@@ -93,6 +93,167 @@ private:
 
 inline int descriptor_distance(const uint8_t *a, const uint8_t *b) { return orbx_descriptor_distance(a, b); }
 
+// The image bounds of a Frame (mnMinX, mnMaxX, mnMinY, mnMaxY; src/Frame.cc:501-523).
+struct Bounds {
+    float min_x, max_x, min_y, max_y;
+};
+
+// orbx::Matcher carries the two constructor arguments of ORB_SLAM2::ORBmatcher (nnratio, checkOri;
+// include/ORBmatcher.h:41) and the device workspace of the searches.  Methods named like the
+// reference's run the same search on plain arrays: frames are (keypoints, descriptors) pairs, map
+// points are their projections and descriptors.
+class Matcher {
+public:
+    static constexpr int TH_LOW = ORBX_TH_LOW, TH_HIGH = ORBX_TH_HIGH, HISTO_LENGTH = ORBX_HISTO_LENGTH;
+
+    explicit Matcher(float nnratio = 0.6f, bool checkOri = true, int device = 0, int max_queries = 4096)
+        : nnratio_(nnratio), check_ori_(checkOri)
+    {
+        check(orbx_matcher_create(device, max_queries, &h_), "orbx_matcher_create");
+    }
+    ~Matcher() { orbx_matcher_destroy(h_); }
+    Matcher(const Matcher &) = delete;
+    Matcher &operator=(const Matcher &) = delete;
+    orbx_matcher *handle() { return h_; }
+
+    static int DescriptorDistance(const uint8_t *a, const uint8_t *b) { return orbx_descriptor_distance(a, b); }
+
+    // Best and second-best database row of every query (the inner loop of SearchByBoW,
+    // src/ORBmatcher.cc:217-242, over a flat candidate list).
+    void match_top2(const uint8_t *queries, int nq, const uint8_t *db, int64_t ndb, std::vector<int32_t> &best,
+                    std::vector<uint16_t> &d1, std::vector<uint16_t> &d2, int64_t idx_base = 0)
+    {
+        best.resize(nq), d1.resize(nq), d2.resize(nq);
+        check(orbx_match_top2(h_, queries, nq, db, ndb, idx_base, best.data(), d1.data(), d2.data()),
+              "orbx_match_top2");
+    }
+    // d1 <= th && d1 < nnratio * d2 (src/ORBmatcher.cc:245-249); returns the number accepted.
+    int ratio_test(const std::vector<uint16_t> &d1, const std::vector<uint16_t> &d2, std::vector<uint8_t> &accept,
+                   int th = TH_LOW) const
+    {
+        accept.resize(d1.size());
+        const int n = orbx_ratio_test((int)d1.size(), d1.data(), d2.data(), th, nnratio_, accept.data());
+        check(n, "orbx_ratio_test");
+        return n;
+    }
+
+    // ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:433-549).  vbPrevMatched holds one
+    // (x, y) pair per keypoint of frame 1 and is updated; vnMatches12 receives indices into frame 2.
+    int SearchForInitialization(const std::vector<orbx_keypoint> &k1, const std::vector<uint8_t> &d1,
+                                const std::vector<orbx_keypoint> &k2, const std::vector<uint8_t> &d2, const Bounds &b,
+                                std::vector<float> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10)
+    {
+        if (vbPrevMatched.size() != k1.size() * 2)
+            throw Error(ORBX_E_ARG, "SearchForInitialization: vbPrevMatched needs 2 floats per keypoint");
+        vnMatches12.assign(k1.size(), -1);
+        const int n = orbx_search_for_initialization(h_, k1.data(), d1.data(), (int)k1.size(), k2.data(), d2.data(),
+                                                     (int)k2.size(), b.min_x, b.max_x, b.min_y, b.max_y,
+                                                     vbPrevMatched.data(), windowSize, nnratio_, check_ori_,
+                                                     vnMatches12.data(), nullptr);
+        check(n, "orbx_search_for_initialization");
+        return n;
+    }
+
+    // Frame::UndistortKeyPoints (src/Frame.cc:467-499) on host keypoints: positions through
+    // cv::undistortPoints with P = K, other fields copied.  cam = fx, fy, cx, cy; dist = k1, k2, p1, p2[, k3].
+    std::vector<orbx_keypoint> UndistortKeyPoints(const std::vector<orbx_keypoint> &keys, const float cam[4],
+                                                  const std::vector<float> &dist)
+    {
+        std::vector<orbx_keypoint> out(keys);
+        if (keys.empty() || dist.empty() || dist[0] == 0.f)
+            return out;
+        std::vector<float> xy(keys.size() * 2);
+        for (size_t i = 0; i < keys.size(); i++)
+            xy[2 * i] = keys[i].x, xy[2 * i + 1] = keys[i].y;
+        check(orbx_undistort_points(h_, xy.data(), (int)keys.size(), cam, dist.data(), (int)dist.size(), xy.data()),
+              "orbx_undistort_points");
+        for (size_t i = 0; i < keys.size(); i++)
+            out[i].x = xy[2 * i], out[i].y = xy[2 * i + 1];
+        return out;
+    }
+    // Frame::ComputeImageBounds (src/Frame.cc:501-523)
+    Bounds ComputeImageBounds(int cols, int rows, const float cam[4], const std::vector<float> &dist)
+    {
+        if (dist.empty() || dist[0] == 0.f)
+            return Bounds{0.f, (float)cols, 0.f, (float)rows};
+        float c[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+        check(orbx_undistort_points(h_, c, 4, cam, dist.data(), (int)dist.size(), c), "orbx_undistort_points");
+        auto mn = [](float a, float b) { return a < b ? a : b; };
+        auto mx = [](float a, float b) { return a > b ? a : b; };
+        return Bounds{mn(c[0], c[4]), mx(c[2], c[6]), mn(c[1], c[3]), mx(c[5], c[7])};
+    }
+
+    // Frame::GetFeaturesInArea (src/Frame.cc:349-407) for nq windows at once over the grid of
+    // Frame::AssignFeaturesToGrid; window q's indices are out[q], in the reference's order.
+    void GetFeaturesInArea(const std::vector<orbx_keypoint> &keys, const Bounds &b, const std::vector<float> &x,
+                           const std::vector<float> &y, const std::vector<float> &r,
+                           const std::vector<int32_t> &minLevel, const std::vector<int32_t> &maxLevel,
+                           std::vector<std::vector<int32_t>> &out, int cap = 512)
+    {
+        const int nq = (int)x.size();
+        std::vector<int32_t> idx((size_t)nq * cap), cnt(nq);
+        check(orbx_features_in_area(h_, keys.data(), (int)keys.size(), b.min_x, b.max_x, b.min_y, b.max_y, x.data(),
+                                    y.data(), r.data(), minLevel.data(), maxLevel.data(), nq, cap, idx.data(),
+                                    cnt.data(), nullptr, nullptr),
+              "orbx_features_in_area");
+        out.resize(nq);
+        for (int q = 0; q < nq; q++) {
+            if (cnt[q] > cap)
+                throw Error(ORBX_E_CAPACITY, "GetFeaturesInArea: window holds more than cap features");
+            out[q].assign(idx.begin() + (size_t)q * cap, idx.begin() + (size_t)q * cap + cnt[q]);
+        }
+    }
+
+    // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-137):
+    // x, y, r, level windows, right coordinates and descriptors of the map points in view; returns
+    // the number of matches, match[s] = feature or -1.
+    struct Sources {
+        std::vector<uint8_t> valid;      // empty: all
+        std::vector<float> x, y, r, xr;  // xr empty: monocular
+        std::vector<int32_t> min_level, max_level;
+        std::vector<uint8_t> desc;     // 32 bytes per source
+        std::vector<uint8_t> blocks;   // empty: every source's map point has observations
+        std::vector<float> angle;      // last-frame form with the rotation check only
+    };
+    int SearchByProjection(const std::vector<orbx_keypoint> &keys, const std::vector<uint8_t> &desc,
+                           const std::vector<float> &uright, const std::vector<uint8_t> &taken, const Bounds &b,
+                           const Sources &s, bool last_frame_form, std::vector<int32_t> &match,
+                           std::vector<int32_t> &feature_match, int th_dist = TH_HIGH)
+    {
+        const int ns = (int)s.x.size();
+        match.assign(ns, -1);
+        feature_match.assign(keys.size(), -1);
+        int32_t nm = 0;
+        auto opt = [](const auto &v) { return v.empty() ? nullptr : v.data(); };
+        check(orbx_search_by_projection(h_, keys.data(), desc.data(), opt(uright), opt(taken), (int)keys.size(),
+                                        b.min_x, b.max_x, b.min_y, b.max_y, opt(s.valid), s.x.data(), s.y.data(),
+                                        s.r.data(), s.min_level.data(), s.max_level.data(), opt(s.xr), s.desc.data(),
+                                        opt(s.blocks), opt(s.angle), ns, last_frame_form ? 0 : 1, nnratio_, th_dist,
+                                        last_frame_form && check_ori_, match.data(), feature_match.data(), &nm),
+              "orbx_search_by_projection");
+        return nm;
+    }
+
+    // MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:248-319) for all segments at once.
+    void ComputeDistinctiveDescriptors(const std::vector<uint8_t> &descriptors, const std::vector<int32_t> &seg_start,
+                                       std::vector<int32_t> &best_idx, std::vector<uint8_t> &best_desc)
+    {
+        const int np = (int)seg_start.size() - 1;
+        best_idx.resize(np > 0 ? np : 0);
+        best_desc.resize((size_t)(np > 0 ? np : 0) * 32);
+        if (np <= 0)
+            return;
+        check(orbx_distinctive_descriptors(h_, descriptors.data(), seg_start.data(), np, best_idx.data(),
+                                           best_desc.data()),
+              "orbx_distinctive_descriptors");
+    }
+
+private:
+    orbx_matcher *h_ = nullptr;
+    float nnratio_;
+    bool check_ori_;
+};
+
 // Frame::ComputeStereoMatches (src/Frame.cc:534-708) on the images the two extractors processed last:
 // fills mvuRight / mvDepth (one entry per left keypoint, -1 where unmatched), returns the match count.
 inline int compute_stereo_matches(Extractor &left, Extractor &right, float mb, float mbf, std::vector<float> &uright,
