@@ -1064,7 +1064,7 @@ struct orbx_matcher {
     uint8_t *d_a, *d_b;
     int *d_pairs;
     uint16_t *d_pd;
-    size_t a_cap, b_cap, pairs_cap;
+    size_t a_cap, b_cap, pairs_cap, pd_cap;
     // segment starts and results of the distinctive-descriptor call
     int *d_seg;
     size_t seg_cap;
@@ -1279,13 +1279,17 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_extractor *left, orbx_ext
     if (!d_uright || !d_depth || !d_nmatches || !(mb > 0.f) || !(mbf > 0.f))
         return ORBX_E_ARG;
     HIP_TRY(hipSetDevice(left->device));
-    if (!left->st_rowstart) {
+    {
         const OrbxGeom &c = left->cap_geom;
         const size_t B = (size_t)left->p.max_batch;
-        HIP_TRY(hipMalloc((void **)&left->st_rowstart, B * (size_t)(left->p.max_height + 1) * sizeof(int)));
-        HIP_TRY(hipMalloc((void **)&left->st_sorted, B * (size_t)c.out_cap * sizeof(uint16_t)));
-        HIP_TRY(hipMalloc((void **)&left->st_sad, B * (size_t)c.out_cap * sizeof(int)));
-        HIP_TRY(hipEventCreateWithFlags(&left->ev_stereo, hipEventDisableTiming));
+        if (!left->st_rowstart)
+            HIP_TRY(hipMalloc((void **)&left->st_rowstart, B * (size_t)(left->p.max_height + 1) * sizeof(int)));
+        if (!left->st_sorted)
+            HIP_TRY(hipMalloc((void **)&left->st_sorted, B * (size_t)c.out_cap * sizeof(uint16_t)));
+        if (!left->st_sad)
+            HIP_TRY(hipMalloc((void **)&left->st_sad, B * (size_t)c.out_cap * sizeof(int)));
+        if (!left->ev_stereo)
+            HIP_TRY(hipEventCreateWithFlags(&left->ev_stereo, hipEventDisableTiming));
     }
     // the right image's batch runs on the right handle's stream
     HIP_TRY(hipEventRecord(left->ev_stereo, right->stream));
@@ -1307,11 +1311,14 @@ extern "C" int orbx_compute_stereo_matches(orbx_extractor *left, orbx_extractor 
     if (frame < 0 || frame >= left->geom.batch || !uright || !depth || !n_keypoints)
         return ORBX_E_ARG;
     HIP_TRY(hipSetDevice(left->device));
-    if (!left->st_uright) {
+    {
         const size_t n = (size_t)left->p.max_batch * left->cap_geom.out_cap;
-        HIP_TRY(hipMalloc((void **)&left->st_uright, n * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&left->st_depth, n * sizeof(float)));
-        HIP_TRY(hipMalloc((void **)&left->st_nmatch, (size_t)left->p.max_batch * sizeof(int)));
+        if (!left->st_uright)
+            HIP_TRY(hipMalloc((void **)&left->st_uright, n * sizeof(float)));
+        if (!left->st_depth)
+            HIP_TRY(hipMalloc((void **)&left->st_depth, n * sizeof(float)));
+        if (!left->st_nmatch)
+            HIP_TRY(hipMalloc((void **)&left->st_nmatch, (size_t)left->p.max_batch * sizeof(int)));
     }
     if (left->st_right != right || left->st_left_serial != left->batch_serial ||
         left->st_right_serial != right->batch_serial || left->st_mb != mb || left->st_mbf != mbf) {
@@ -1437,17 +1444,8 @@ extern "C" int orbx_search_for_initialization(orbx_matcher *m, const orbx_keypoi
         HIP_TRY(hipSetDevice(m->device));
         int rc = grow(&m->d_a, &m->a_cap, (size_t)n1 * 32, m->stream);
         if (rc == ORBX_OK) rc = grow(&m->d_b, &m->b_cap, (size_t)n2 * 32, m->stream);
-        if (rc == ORBX_OK) {
-            // pairs (2 ints each) and their distances share one growth step
-            const size_t before = m->pairs_cap;
-            rc = grow(&m->d_pairs, &m->pairs_cap, (size_t)np * 2, m->stream);
-            if (rc == ORBX_OK && m->pairs_cap != before) {
-                if (m->d_pd)
-                    HIP_TRY(hipFree(m->d_pd));
-                m->d_pd = nullptr;
-                HIP_TRY(hipMalloc((void **)&m->d_pd, m->pairs_cap / 2 * sizeof(uint16_t) + 16));
-            }
-        }
+        if (rc == ORBX_OK) rc = grow(&m->d_pairs, &m->pairs_cap, (size_t)np * 2, m->stream);
+        if (rc == ORBX_OK) rc = grow(&m->d_pd, &m->pd_cap, (size_t)np + 8, m->stream);
         if (rc != ORBX_OK)
             return rc;
         HIP_TRY(hipMemcpyAsync(m->d_a, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, m->stream));
@@ -1787,6 +1785,30 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const f
         (n2 > 0 && (!desc2 || !angle2)) || (m2 > 0 && (!node_ids2 || !node_start2 || !node_items2)))
         return ORBX_E_ARG;
     const int I1 = E1 > 0 ? node_start1[E1] : 0, I2 = m2 > 0 ? node_start2[m2] : 0;
+    // The kernels index with these tables: every offset must ascend from 0 and every item must name a
+    // feature of its own key frame (side 1) or of the frame (side 2).
+    if (feat_start[0] != 0 || node_kf_start[0] != 0 || (E1 > 0 && node_start1[0] != 0) || (m2 > 0 && node_start2[0] != 0) ||
+        I1 < 0 || I2 < 0)
+        return ORBX_E_ARG;
+    for (int b = 0; b < nb; b++) {
+        if (feat_start[b + 1] < feat_start[b] || node_kf_start[b + 1] < node_kf_start[b])
+            return ORBX_E_ARG;
+        const int nfeat = feat_start[b + 1] - feat_start[b];
+        for (int e = node_kf_start[b]; e < node_kf_start[b + 1]; e++) {
+            if (node_start1[e + 1] < node_start1[e] || node_start1[e + 1] > I1)
+                return ORBX_E_ARG;
+            for (int j = node_start1[e]; j < node_start1[e + 1]; j++)
+                if (node_items1[j] < 0 || node_items1[j] >= nfeat)
+                    return ORBX_E_ARG;
+        }
+    }
+    for (int e = 0; e < m2; e++) {
+        if (node_start2[e + 1] < node_start2[e] || node_start2[e + 1] > I2)
+            return ORBX_E_ARG;
+        for (int j = node_start2[e]; j < node_start2[e + 1]; j++)
+            if (node_items2[j] < 0 || node_items2[j] >= n2)
+                return ORBX_E_ARG;
+    }
     // the key frame of every node entry
     std::vector<int> node_kf((size_t)std::max(E1, 1));
     for (int b = 0; b < nb; b++)

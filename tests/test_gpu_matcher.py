@@ -336,6 +336,19 @@ def test_search_by_bow_vs_oracle(oracle, strict, ratio, ori):
                  node_ids=np.zeros(0, np.int32), node_start=np.zeros(1, np.int32), node_items=np.zeros(0, np.int32))
     nm, m12, m21 = m.SearchByBoW([empty], frame)
     assert nm[0] == 0 and (m21 == -1).all()
+    # index tables that point outside their arrays are refused before anything reaches the GPU
+    for side, key, bad in (("kf", "node_items", len(kfs[3]["desc"])), ("kf", "node_items", -1),
+                           ("frame", "node_items", n2), ("kf", "node_start", None)):
+        k, f = dict(kfs[3]), dict(frame)
+        tgt = k if side == "kf" else f
+        arr = np.array(tgt[key], np.int32)
+        if bad is None:
+            arr[1] = arr[-1] + 5      # an offset beyond the item list
+        else:
+            arr[len(arr) // 2] = bad
+        tgt[key] = arr
+        with pytest.raises(orbx.OrbxError):
+            m.SearchByBoW([k], f)
 
 
 def test_frame_grid_and_area_queries_vs_oracle(oracle):
