@@ -185,13 +185,12 @@ def main():
     stage_ms = {k: v / max(nprof, 1) for k, v in stage_ms.items()}
     launch_frames = eyes[0][1]
 
-    hamming_sharded = None
-    if dist_path and not args.no_hamming:
-        try:
-            hamming_sharded = bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev)
-        except Exception as exc:  # the frames/s line must survive a failure of this extra measurement
-            hamming_sharded = {"error": repr(exc)}
     if rank != 0:
+        # the sharded matcher measurement needs every rank; a rank that cannot finish it leaves after the
+        # same limit as rank 0, so that no rank waits in a collective forever
+        if dist_path and not args.no_hamming:
+            guarded_sharded_hamming(lambda: bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev),
+                                    None)
         if dist_path:
             dist.destroy_process_group()
         return
@@ -238,14 +237,42 @@ def main():
 
     if not dist_path and not args.no_hamming:
         out["hamming"] = bench_hamming(orbx, torch, stream)
-    if dist_path and hamming_sharded is not None:
-        out["hamming"] = hamming_sharded
+    if dist_path and not args.no_hamming:
+        # the frames/s line must survive a failure or a hang of this extra measurement
+        out["hamming"] = guarded_sharded_hamming(
+            lambda: bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev), out)
     if not dist_path and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host, w, nfeat, args.cpu_seconds)
         out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
     print(json.dumps(out), flush=True)
     if dist_path:
         dist.destroy_process_group()
+
+
+SHARDED_HAMMING_LIMIT_S = 150
+
+
+def guarded_sharded_hamming(fn, out):
+    """Runs the sharded matcher measurement under a time limit.  An exception becomes an error entry; at
+    the limit (a rank stuck in a collective because another rank failed) rank 0 prints the line it has
+    (`out`, None on other ranks) and every rank leaves the process."""
+    import threading
+
+    def bail():
+        if out is not None:
+            out["hamming"] = {"error": "sharded matcher measurement did not finish in %d s" % SHARDED_HAMMING_LIMIT_S}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    timer = threading.Timer(SHARDED_HAMMING_LIMIT_S, bail)
+    timer.daemon = True
+    timer.start()
+    try:
+        return fn()
+    except Exception as exc:
+        return {"error": repr(exc)}
+    finally:
+        timer.cancel()
 
 
 def _committed(name):
@@ -310,7 +337,7 @@ def bench_hamming(orbx, torch, stream):
     best = torch.zeros(nq, dtype=torch.int32, device="cuda")
     d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
     d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
-    m = orbx.ORBmatcher(0.75)
+    m = orbx.ORBmatcher(0.75, device=torch.cuda.current_device())
     m.set_stream(stream.cuda_stream)
 
     def run():
@@ -359,7 +386,8 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
     best = torch.zeros(nq, dtype=torch.int32, device="cuda")
     d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
     d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
-    m = orbx.ORBmatcher(0.75)
+    # the matcher on this rank's GPU: its launches make that device current
+    m = orbx.ORBmatcher(0.75, device=torch.cuda.current_device())
     m.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def local(qq, base):
