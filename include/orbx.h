@@ -267,7 +267,11 @@ int orbx_features_in_area_device(orbx_matcher *m, const orbx_keypoint *d_keypoin
 /* ORBmatcher::SearchByProjection in the two forms the tracking thread runs on every frame:
  *   use_second = 1: (Frame &F, const vector<MapPoint*> &vpMapPoints, th), src/ORBmatcher.cc:46-137;
  *   use_second = 0: (Frame &CurrentFrame, const Frame &LastFrame, th, bMono), :1412-1566, with its
- *                   rotation check when check_orientation is set.
+ *                   rotation check when check_orientation is 1.  The relocalisation form (Frame &CurrentFrame,
+ *                   KeyFrame *pKF, sAlreadyFound, th, ORBdist), :1568-1690, is this search with th_dist =
+ *                   ORBdist, taken[i] = mvpMapPoints[i] != NULL (:1636-1637), src_angle = pKF->mvKeysUn[i].angle
+ *                   and check_orientation = 2: its histogram bins with 1.0f/HISTO_LENGTH (:1581) where the
+ *                   other form uses HISTO_LENGTH/360.0f (:1420).
  * The frame: n <= 32768 keypoints (mvKeysUn) with descriptors, uright = mvuRight or NULL (monocular),
  * taken[i] != 0 where mvpMapPoints[i] has Observations() > 0 (NULL: none), the grid bounds.
  * The ns sources, in the reference's order, after what precedes the window query there: valid[s] = the

@@ -1511,7 +1511,10 @@ int orc_trace_sizeof(void) { return (int)sizeof(orc_trace); }
  *                   best > nnratio * second (:118-126);
  *   use_second = 0: (Frame &CurrentFrame, const Frame &LastFrame, th, bMono), :1412-1566 - best only
  *                   (:1500-1520), then the rotation histogram with factor HISTO_LENGTH/360.0f (:1421,
- *                   :1528-1560) when check_orientation is set.
+ *                   :1528-1560) when check_orientation is 1.  The relocalisation form (Frame &CurrentFrame,
+ *                   KeyFrame *pKF, sAlreadyFound, th, ORBdist), :1568-1690, is the same search with
+ *                   th_dist = ORBdist, taken = "holds any map point" (:1636-1637) and check_orientation = 2:
+ *                   its histogram uses factor 1.0f/HISTO_LENGTH (:1581).
  * The caller has done what precedes the window query: source s is skipped unless valid[s] (mbTrackInView
  * and not bad; or a last-frame map point that is no outlier and projects into the image), (x, y) is the
  * projection, r the window radius (r * mvScaleFactors[level], resp. th * mvScaleFactors[octave]),
@@ -1539,7 +1542,7 @@ int orc_search_by_projection(const orc_keypoint *kps, const uint8_t *desc, const
         memcpy(taken, taken_in, (size_t)n);
     for (int i = 0; i < n; i++)
         feature_match[i] = -1;
-    const float factor = HISTO_LENGTH / 360.0f;
+    const float factor = check_orientation == 2 ? 1.0f / HISTO_LENGTH : HISTO_LENGTH / 360.0f;
     int nmatches = 0;
     for (int s = 0; s < ns; s++) {
         match[s] = -1;

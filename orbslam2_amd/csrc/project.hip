@@ -179,11 +179,12 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
     }
 }
 
-// rotation histogram of the accepted matches with factor HISTO_LENGTH/360.0f (:1421, :1528-1540),
-// ComputeThreeMaxima (:1698-1739) and the removal loop (:1546-1557); one workgroup
+// rotation histogram of the accepted matches with factor HISTO_LENGTH/360.0f (:1421, :1528-1540) or, for
+// the key-frame form, 1.0f/HISTO_LENGTH (:1581, :1654-1663), ComputeThreeMaxima (:1698-1739) and the
+// removal loop (:1546-1557, :1667-1685); one workgroup
 __global__ __launch_bounds__(256) void k_proj_finish(const orbx_keypoint *__restrict__ kp, const float *__restrict__ src_angle,
                                                      const int32_t *__restrict__ match, int32_t *__restrict__ feature_match,
-                                                     int32_t *__restrict__ result, int ns)
+                                                     int32_t *__restrict__ result, int ns, float factor)
 {
     __shared__ int hist[PROJ_HISTO];
     __shared__ int s_removed;
@@ -193,7 +194,6 @@ __global__ __launch_bounds__(256) void k_proj_finish(const orbx_keypoint *__rest
     if (tid == 0)
         s_removed = 0;
     __syncthreads();
-    const float factor = (float)PROJ_HISTO / 360.0f;
     auto bin_of = [&](int s, int m) {
         float rot = __fsub_rn(src_angle[s], kp[m].angle);
         if (rot < 0.0f)
@@ -267,6 +267,7 @@ hipError_t orbx_launch_search_by_projection(const orbx_keypoint *d_kp, const uin
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !check_orientation || ns <= 0)
         return e;
-    k_proj_finish<<<1, 256, 0, s>>>(d_kp, d_src_angle, d_match, d_feature_match, d_result, ns);
+    const float factor = check_orientation == 2 ? 1.0f / (float)PROJ_HISTO : (float)PROJ_HISTO / 360.0f;
+    k_proj_finish<<<1, 256, 0, s>>>(d_kp, d_src_angle, d_match, d_feature_match, d_result, ns, factor);
     return hipGetLastError();
 }

@@ -209,7 +209,7 @@ class ORBmatcher:
         L.check(self._lib.orbx_search_by_projection(
             self._handle(), L.ptr(kps), L.ptr(desc), opt(ur), opt(tk), n, bounds[0], bounds[1], bounds[2], bounds[3],
             opt(va), L.ptr(qx), L.ptr(qy), L.ptr(qr), L.ptr(lo), L.ptr(hi), opt(xr_), L.ptr(sd), opt(bl), opt(an), ns,
-            int(bool(use_second)), float(self.mfNNratio), int(th_dist), int(bool(check_orientation)), L.ptr(match),
+            int(bool(use_second)), float(self.mfNNratio), int(th_dist), int(check_orientation), L.ptr(match),
             L.ptr(fmatch), C.byref(nm)), "orbx_search_by_projection")
         return int(nm.value), match[:ns].copy(), fmatch[:n].copy()
 
@@ -245,6 +245,19 @@ class ORBmatcher:
         return self.search_by_projection(keypoints, descriptors, bounds, u, v, r, lo, hi, mp_desc, uright=uright,
                                          taken=taken, valid=valid, xr=ur, blocks=blocks, src_angle=last_angle,
                                          use_second=False, th_dist=self.TH_HIGH, check_orientation=check_orientation)
+
+    def SearchByProjectionKeyFrame(self, keypoints, descriptors, bounds, scale_factors, valid, u, v, predicted_level,
+                                   kf_angle, mp_desc, th, ORBdist, *, taken=None):
+        """ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, sAlreadyFound, th, ORBdist)
+        (src/ORBmatcher.cc:1568-1690, Tracking::Relocalization): valid = the key frame's map point exists, is not
+        bad, not in sAlreadyFound, projects into the image and lies in its distance range (:1585-1617); (u, v) its
+        projection, predicted_level = PredictScale, kf_angle = pKF->mvKeysUn[i].angle, taken = the frame's
+        features that hold a map point.  Best only, accepted if best <= ORBdist; histogram factor 1/HISTO_LENGTH."""
+        lvl = np.ascontiguousarray(predicted_level, np.int32)
+        r = (np.float32(th) * np.asarray(scale_factors, np.float32)[lvl]).astype(np.float32)
+        return self.search_by_projection(keypoints, descriptors, bounds, u, v, r, lvl - 1, lvl + 1, mp_desc, taken=taken,
+                                         valid=valid, src_angle=kf_angle, use_second=False, th_dist=ORBdist,
+                                         check_orientation=2 if self.mbCheckOrientation else 0)
 
     def UndistortKeyPoints(self, keypoints, cam, dist):
         """Frame::UndistortKeyPoints (src/Frame.cc:467-499): keypoints = KEYPOINT_DTYPE array (mvKeys), cam = (fx,

@@ -566,6 +566,35 @@ def test_search_by_projection_last_frame_vs_oracle(oracle, mode, ori):
         assert (fm == -2).sum() > 10        # the planted 140-degree rotations fall outside the three maxima
 
 
+@pytest.mark.parametrize("ori,orbdist", [(True, 100), (True, 64), (False, 100)])
+def test_search_by_projection_key_frame_form_vs_oracle(oracle, ori, orbdist):
+    """src/ORBmatcher.cc:1568-1690 (Tracking::Relocalization): best only against ORBdist, features that hold any
+    map point skipped, rotation histogram with factor 1/HISTO_LENGTH (13 bins in use)."""
+    sc = _projection_scene(41, stereo=False)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    bounds = (0.0, 1241.0, 0.0, 376.0)
+    lvl = np.clip(sc["lvl"], 0, 6)
+    # rotations spread over the whole circle so that more than three of the 13 bins fill
+    rng = np.random.default_rng(5)
+    angle = ((sc["angle"] + rng.choice([0, 0, 0, 40, 80, 170, 250], size=len(sc["angle"]))) % 360).astype(np.float32)
+    m = orbx.ORBmatcher(0.9, ori)
+    nm, match, fm = m.SearchByProjectionKeyFrame(sc["kps"], sc["desc"], bounds, scale, sc["valid"], sc["x"], sc["y"], lvl,
+                                                 angle, sc["sd"], 10.0, orbdist, taken=sc["taken"])
+    r = (np.float32(10.0) * scale[lvl]).astype(np.float32)
+    onm, omatch, ofm = oracle.search_by_projection(sc["kps"], sc["desc"], bounds, sc["x"], sc["y"], r, lvl - 1, lvl + 1,
+                                                   sc["sd"], 0.9, taken=sc["taken"], valid=sc["valid"], src_angle=angle,
+                                                   use_second=False, th_dist=orbdist, check_orientation=2 if ori else 0)
+    assert nm == onm and nm > 300
+    assert np.array_equal(match, omatch) and np.array_equal(fm, ofm)
+    if ori:
+        assert (fm == -2).sum() > 10
+        # the other histogram would have cleared a different set
+        _, _, ofm1 = oracle.search_by_projection(sc["kps"], sc["desc"], bounds, sc["x"], sc["y"], r, lvl - 1, lvl + 1,
+                                                 sc["sd"], 0.9, taken=sc["taken"], valid=sc["valid"], src_angle=angle,
+                                                 use_second=False, th_dist=orbdist, check_orientation=1)
+        assert not np.array_equal(ofm, ofm1)
+
+
 def test_search_by_projection_edges(oracle):
     """No sources, no features, and a window that holds more candidates than the kernel's lists (an error,
     not a wrong answer)."""

@@ -454,3 +454,26 @@ def test_search_by_projection_known_answers():
     assert nm == 0
     nm, match, _ = run([500], [300], [5], [0], [0], zero, uright=ur, xr=np.array([484], np.float32))
     assert list(match) == [3]
+
+
+def test_search_by_projection_histogram_factor_of_the_key_frame_form():
+    """The relocalisation form bins rotations with 1.0f/HISTO_LENGTH (src/ORBmatcher.cc:1581), the last-frame
+    form with HISTO_LENGTH/360.0f (:1420): rotations of 5 and 10 degrees share bin 0 in the first and fall into
+    bins 0 and 1 in the second, where the single 10-degree match is then outside the three maxima."""
+    from oracle import pyoracle as orc
+    import orbslam2_amd as orbx
+    n = 10
+    kps = np.zeros(n, orbx.KEYPOINT_DTYPE)
+    kps["x"] = 50 + 40 * np.arange(n)
+    kps["y"] = 100
+    desc = orbx.synth_descriptors(5, n)
+    rot = np.array([5, 5, 5, 5, 10, 100, 100, 100, 200, 200], np.float32)
+    bounds = (0.0, 640.0, 0.0, 480.0)
+    args = (kps, desc, bounds, kps["x"], kps["y"], np.full(n, 5, np.float32), np.zeros(n, np.int32),
+            np.zeros(n, np.int32), desc, 0.9)
+    nm1, m1, f1 = orc.search_by_projection(*args, src_angle=rot, use_second=False, check_orientation=1)
+    assert nm1 == 9 and list(m1) == list(range(n)) and f1[4] == -2 and (np.delete(f1, 4) == np.delete(np.arange(n), 4)).all()
+    nm2, m2, f2 = orc.search_by_projection(*args, src_angle=rot, use_second=False, check_orientation=2)
+    assert nm2 == 10 and list(f2) == list(range(n))
+    nm0, _, f0 = orc.search_by_projection(*args, src_angle=rot, use_second=False, check_orientation=0)
+    assert nm0 == 10 and list(f0) == list(range(n))
