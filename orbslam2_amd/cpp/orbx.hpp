@@ -204,9 +204,14 @@ public:
         }
     }
 
-    // ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:46-137):
-    // x, y, r, level windows, right coordinates and descriptors of the map points in view; returns
-    // the number of matches, match[s] = feature or -1.
+    // ORBmatcher::SearchByProjection from the projections of the map points (x, y, window radius, level
+    // window, right coordinate, descriptor per source); returns the number of matches, match[s] = feature
+    // or -1, feature_match[i] = source or -1 (-2: cleared by the rotation check).  form selects the rules:
+    //   MapPoints  (Frame&, const vector<MapPoint*>&, th), src/ORBmatcher.cc:46-137: best and second best;
+    //   LastFrame  (Frame&, const Frame&, th, bMono), :1412-1566: best only, rotation check;
+    //   KeyFrame   (Frame&, KeyFrame*, sAlreadyFound, th, ORBdist), :1568-1690: best only against
+    //              th_dist = ORBdist, rotation check with the histogram factor 1/HISTO_LENGTH.
+    enum Form { MapPoints = 0, LastFrame = 1, KeyFrame = 2 };
     struct Sources {
         std::vector<uint8_t> valid;      // empty: all
         std::vector<float> x, y, r, xr;  // xr empty: monocular
@@ -217,7 +222,7 @@ public:
     };
     int SearchByProjection(const std::vector<orbx_keypoint> &keys, const std::vector<uint8_t> &desc,
                            const std::vector<float> &uright, const std::vector<uint8_t> &taken, const Bounds &b,
-                           const Sources &s, bool last_frame_form, std::vector<int32_t> &match,
+                           const Sources &s, int form, std::vector<int32_t> &match,
                            std::vector<int32_t> &feature_match, int th_dist = TH_HIGH)
     {
         const int ns = (int)s.x.size();
@@ -228,8 +233,9 @@ public:
         check(orbx_search_by_projection(h_, keys.data(), desc.data(), opt(uright), opt(taken), (int)keys.size(),
                                         b.min_x, b.max_x, b.min_y, b.max_y, opt(s.valid), s.x.data(), s.y.data(),
                                         s.r.data(), s.min_level.data(), s.max_level.data(), opt(s.xr), s.desc.data(),
-                                        opt(s.blocks), opt(s.angle), ns, last_frame_form ? 0 : 1, nnratio_, th_dist,
-                                        last_frame_form && check_ori_, match.data(), feature_match.data(), &nm),
+                                        opt(s.blocks), opt(s.angle), ns, form == MapPoints ? 1 : 0, nnratio_, th_dist,
+                                        (form != MapPoints && check_ori_) ? form : 0, match.data(),
+                                        feature_match.data(), &nm),
               "orbx_search_by_projection");
         return nm;
     }

@@ -15,6 +15,8 @@
 // address (a node created later counts as larger).  All nodes with >1 key were created in the
 // preceding round, so the creation index inside that round is enough.
 // Afterwards each node keeps its best-response key, the first such key in candidate order (:791-810).
+#include <cstdlib>
+
 #include "orbx_internal.h"
 
 struct OctLevel {
@@ -47,7 +49,9 @@ struct OctLds {
     __device__ __forceinline__ int *spos() const { return base + 15 * cap; }   // new position of a surviving node
 };
 #define OCT_ARRAYS 16
-#define OCT_TAIL_INTS 8  // wave sums of the block scan + the root count, behind the arrays
+#define OCT_NT_MAX 512  // threads of the larger workgroup form
+#define OCT_WIDE_MAX_BATCH 8  // batches up to this many frames use it
+#define OCT_TAIL_INTS (OCT_NT_MAX / 64 + 4)  // wave sums of the block scan + the root count, behind the arrays
 
 size_t orbx_octree_lds_bytes(int node_cap) { return ((size_t)OCT_ARRAYS * node_cap + OCT_TAIL_INTS) * sizeof(int); }
 
@@ -62,8 +66,9 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
-// exclusive prefix of one value per thread over the 256-thread block; *total = block sum
-__device__ __forceinline__ int block_excl_scan(int v, int *wsum /* 4 ints of LDS */, int *total)
+// exclusive prefix of one value per thread over the workgroup; *total = its sum
+template <int NT>
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum /* NT/64 ints of LDS */, int *total)
 {
     const int inc = wave_incl_scan(v);
     const int wv = threadIdx.x >> 6;
@@ -71,10 +76,14 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wsum /* 4 ints of LDS
     if ((threadIdx.x & 63) == 63)
         wsum[wv] = inc;
     __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; i++)
-        base += wsum[i];
-    *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int base = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        const int w = wsum[i];
+        base += i < wv ? w : 0;
+        all += w;
+    }
+    *total = all;
     return base + inc - v;
 }
 
@@ -94,9 +103,9 @@ __device__ __forceinline__ int quadrant_of(uint32_t xy, int bx, int by)
 // candidate counts iff its score A = resp+1 exceeds t_ini, or its cell has none such and A exceeds t_min
 // (src/ORBextractor.cc:868-878).
 // out_*: kept keypoints in list order (xy as given, plus `add` on both coordinates); out_idx optional.
-// KMAX > 0: every thread keeps its (at most KMAX) candidates in registers, n <= 256*KMAX;
+// KMAX > 0: every thread keeps its (at most KMAX) candidates in registers, n <= NT*KMAX;
 // KMAX == 0: candidates stay in global memory (`node` is the scratch array), any n.
-template <int KMAX>
+template <int KMAX, int NT>
 __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, const uint8_t *__restrict__ resp,
                                             const uint32_t *__restrict__ key, const uint8_t *__restrict__ cell_ini,
                                             int t_ini, int t_min, uint16_t *__restrict__ node, int n, int quota,
@@ -108,7 +117,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
     // all LDS lives in the one dynamic array, so its base alignment is not disturbed
     extern __shared__ __attribute__((aligned(16))) int lds[];
     int *wsum = lds + (size_t)OCT_ARRAYS * cap;
-    int &sh_size = wsum[4];
+    int &sh_size = wsum[NT / 64];
     const OctLds L{lds, cap};
     const int tid = threadIdx.x;
     if (n <= 0) {
@@ -127,12 +136,12 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         if constexpr (KMAX > 0) {
 #pragma unroll
             for (int j = 0; j < KMAX; j++) {
-                const int k = tid + 256 * j;
+                const int k = tid + NT * j;
                 if (k < n)
                     fn(j, k);
             }
         } else {
-            for (int k = tid; k < n; k += 256)
+            for (int k = tid; k < n; k += NT)
                 fn(0, k);
         }
     };
@@ -155,7 +164,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
     };
 
     // ---- roots (:587-631) ----
-    for (int i = tid; i < n_ini; i += 256) {
+    for (int i = tid; i < n_ini; i += NT) {
         const int ulx = (int)(hx * (float)i), urx = (int)(hx * (float)(i + 1));
         L.bx(1)[i] = ulx | (urx << 16);
         L.by(1)[i] = 0 | (region_h << 16);
@@ -167,7 +176,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         uint32_t rk[KR];
 #pragma unroll
         for (int j = 0; j < KMAX; j++) {
-            const int k = tid + 256 * j;
+            const int k = tid + NT * j;
             rxy[j] = k < n ? xy[k] : 0u;
             rr[j] = k < n ? resp[k] : (uint8_t)0;
             rk[j] = (k < n && key) ? key[k] : (uint32_t)k;
@@ -224,7 +233,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         const int prev_size = size;
         int *bx = L.bx(cur), *by = L.by(cur), *cnt = L.cnt(cur), *seq = L.seq(cur);
         int *nbx = L.bx(cur ^ 1), *nby = L.by(cur ^ 1), *ncnt = L.cnt(cur ^ 1), *nseq = L.seq(cur ^ 1);
-        const int per = (size + 255) / 256;
+        const int per = (size + NT - 1) / NT;
         const int lo = min(tid * per, size), hi = min(lo + per, size);
 
         // ---- processing order of the nodes that hold more than one key ----
@@ -234,7 +243,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             L.cc(0)[i] = L.cc(1)[i] = L.cc(2)[i] = L.cc(3)[i] = 0;
         }
         int m;
-        int ebase = block_excl_scan(my_e, wsum, &m);
+        int ebase = block_excl_scan<NT>(my_e, wsum, &m);
         if (!last_kind) {
             for (int i = lo; i < hi; i++)
                 L.prank()[i] = cnt[i] >= 2 ? ebase++ : -1;
@@ -263,7 +272,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             int enc[KR];
 #pragma unroll
             for (int j = 0; j < KMAX; j++) {
-                const int k = tid + 256 * j;
+                const int k = tid + NT * j;
                 const int i = rnode[j];
                 const bool live = k < n && i != OCT_DROPPED;
                 const int ii = live ? i : 0;
@@ -284,7 +293,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         __syncthreads();
 
         // ---- how many nodes are processed: all, or up to the one that brings the list to N ----
-        const int rper = (m + 255) / 256;
+        const int rper = (m + NT - 1) / NT;
         const int rlo = min(tid * rper, m), rhi = min(rlo + rper, m);
         int my_nz = 0;
         for (int r = rlo; r < rhi; r++) {
@@ -292,7 +301,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             my_nz += (L.cc(0)[i] > 0) + (L.cc(1)[i] > 0) + (L.cc(2)[i] > 0) + (L.cc(3)[i] > 0);
         }
         int nz_total;
-        int run = block_excl_scan(my_nz, wsum, &nz_total);
+        int run = block_excl_scan<NT>(my_nz, wsum, &nz_total);
         int below = 0;  // processed nodes after which the list is still shorter than N
         for (int r = rlo; r < rhi; r++) {
             const int i = L.order()[r];
@@ -303,7 +312,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         int t = m;
         if (last_kind) {
             int t0;
-            block_excl_scan(below, wsum, &t0);
+            block_excl_scan<NT>(below, wsum, &t0);
             t = min(t0 + 1, m);
         }
         __syncthreads();
@@ -314,7 +323,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         for (int i = lo; i < hi; i++)
             my_s += !(L.prank()[i] >= 0 && L.prank()[i] < t);
         int nsurv;
-        int sbase = block_excl_scan(my_s, wsum, &nsurv);
+        int sbase = block_excl_scan<NT>(my_s, wsum, &nsurv);
         const int new_size = children + nsurv;
         if (new_size > cap) {
             // cannot happen for a correctly sized list; reported instead of writing out of bounds
@@ -379,12 +388,12 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             break;
         if (!last_kind) {
             int my_x = 0;
-            const int per2 = (size + 255) / 256;
+            const int per2 = (size + NT - 1) / NT;
             const int lo2 = min(tid * per2, size), hi2 = min(lo2 + per2, size);
             for (int i = lo2; i < hi2; i++)
                 my_x += L.cnt(cur)[i] >= 2;
             int n_expand;
-            block_excl_scan(my_x, wsum, &n_expand);
+            block_excl_scan<NT>(my_x, wsum, &n_expand);
             if (size + 3 * n_expand > N)
                 last_kind = true;
         }
@@ -394,7 +403,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
     // ---- best key of every node (:791-810): largest response, first in candidate order ----
     __syncthreads();
     unsigned long long *best = reinterpret_cast<unsigned long long *>(L.cc(0));  // cc[0],cc[1] are adjacent
-    for (int i = tid; i < size; i += 256)
+    for (int i = tid; i < size; i += NT)
         best[i] = 0ull;
     __syncthreads();
     for_keys([&](int j, int k) {
@@ -421,18 +430,22 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         *out_n = size;
 }
 
-#define OCT_KMAX 12  // candidates per thread held in registers: levels with up to 3072 candidates
+// Candidates per thread held in registers: 16 in the wide form (levels with up to 8192 candidates), 14 in the
+// narrow form (3584; measured: 12, 14 and 16 give the same batch throughput, 14 the shortest kernel).
+#define OCT_KMAX_WIDE 16
+#define OCT_KMAX_NARROW 14
 
-template <typename... Args> __device__ __forceinline__ void octree_dispatch(int n, Args... args)
+template <int NT, int KMAX, typename... Args> __device__ __forceinline__ void octree_dispatch(int n, Args... args)
 {
     // n is uniform over the workgroup
-    if (n <= 256 * OCT_KMAX)
-        octree_body<OCT_KMAX>(args...);
+    if (n <= NT * KMAX)
+        octree_body<KMAX, NT>(args...);
     else
-        octree_body<0>(args...);
+        octree_body<0, NT>(args...);
 }
 
-__global__ __launch_bounds__(256) void k_octree(const uint32_t *__restrict__ cand_xy,
+template <int NT, int KMAX>
+__global__ __launch_bounds__(NT) void k_octree(const uint32_t *__restrict__ cand_xy,
                                                 const uint8_t *__restrict__ cand_resp,
                                                 const uint32_t *__restrict__ cand_key,
                                                 const uint8_t *__restrict__ cell_ini, uint16_t *__restrict__ cand_node,
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(256) void k_octree(const uint32_t *__restrict__ can
     const size_t cb = (size_t)f * a.cand_per_frame + L.cand_base;
     const size_t kb = (size_t)f * a.kp_per_frame + L.kp_base;
     const int n = min(ncand[f * a.nlevels + lvl], L.cand_cap);  // an overflow is reported by the producer
-    octree_dispatch(n, cand_xy + cb, cand_resp + cb, cand_key + cb,
+    octree_dispatch<NT, KMAX>(n, cand_xy + cb, cand_resp + cb, cand_key + cb,
                     cell_ini + (size_t)f * a.cells_per_frame + L.cell_base, a.t_ini, a.t_min, cand_node + cb, n,
                     L.quota, L.n_ini, L.hx, L.region_h, L.node_cap, (int)ORBX_BORDER, kept_xy + kb, kept_resp + kb,
                     (int *)nullptr, nkept + f * a.nlevels + lvl, status);
@@ -468,24 +481,34 @@ hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream
     }
     // every level carves its own node_cap out of an allocation sized for the largest level
     const size_t lds = orbx_octree_lds_bytes(cap);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-    }
-    k_octree<<<dim3(g.nlevels, g.batch), 256, orbx_octree_lds_bytes(cap), s>>>(
-        b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.cand_node, b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status,
-        a);
-    return hipGetLastError();
+    // Few frames: a level's candidates spread over 512 threads (the chain of rounds is the latency of a
+    // single call).  Many frames: 256 threads, so that more workgroups of other kernels fit beside these.
+    static const int forced = [] {
+        const char *e = getenv("ORBX_OCTREE_THREADS");
+        return e ? atoi(e) : 0;
+    }();
+    const bool wide = forced ? forced >= 512 : g.batch <= OCT_WIDE_MAX_BATCH;
+    auto launch = [&](auto kernel, int nt) -> hipError_t {
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess)
+                return e;
+        }
+        kernel<<<dim3(g.nlevels, g.batch), nt, lds, s>>>(b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.cand_node,
+                                                         b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status, a);
+        return hipGetLastError();
+    };
+    return wide ? launch(k_octree<OCT_NT_MAX, OCT_KMAX_WIDE>, OCT_NT_MAX) : launch(k_octree<256, OCT_KMAX_NARROW>, 256);
 }
 
-__global__ __launch_bounds__(256) void k_octree_single(const uint32_t *xy, const uint8_t *resp, uint16_t *node, int n,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_octree_single(const uint32_t *xy, const uint8_t *resp, uint16_t *node, int n,
                                                        int quota, int n_ini, float hx, int region_h, int cap,
                                                        uint32_t *out_xy, uint8_t *out_resp, int *out_idx, int *out_n,
                                                        int *status)
 {
-    octree_dispatch(n, xy, resp, (const uint32_t *)nullptr, (const uint8_t *)nullptr, 0, 0, node, n, quota, n_ini, hx,
+    octree_dispatch<NT, OCT_KMAX_WIDE>(n, xy, resp, (const uint32_t *)nullptr, (const uint8_t *)nullptr, 0, 0, node, n, quota, n_ini, hx,
                     region_h, cap, 0, out_xy, out_resp, out_idx, out_n, status);
 }
 
@@ -497,13 +520,12 @@ hipError_t orbx_launch_octree_single(const uint32_t *d_xy, const uint8_t *d_resp
     const float hx = (float)region_w / (float)n_ini;
     const size_t lds = orbx_octree_lds_bytes(node_cap);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree_single),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree_single<OCT_NT_MAX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
-    k_octree_single<<<1, 256, lds, s>>>(d_xy, d_resp, d_node, n, quota, n_ini, hx,
-                                                                    region_h, node_cap, d_out_xy, d_out_resp,
-                                                                    d_out_idx, d_nout, d_status);
+    k_octree_single<OCT_NT_MAX><<<1, OCT_NT_MAX, lds, s>>>(d_xy, d_resp, d_node, n, quota, n_ini, hx, region_h, node_cap,
+                                                           d_out_xy, d_out_resp, d_out_idx, d_nout, d_status);
     return hipGetLastError();
 }

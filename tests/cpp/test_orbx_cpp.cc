@@ -109,7 +109,7 @@ int main(int argc, char **argv)
         }
         src.desc = desc;
         std::vector<int32_t> pm, pfm;
-        const int nproj = mt.SearchByProjection(kru, dr, {}, {}, bd, src, true, pm, pfm);
+        const int nproj = mt.SearchByProjection(kru, dr, {}, {}, bd, src, orbx::Matcher::LastFrame, pm, pfm);
         long long psum = 0;
         for (size_t i = 0; i < pm.size(); i++)
             psum += (long long)(pm[i] + 1) * (long long)(i + 1);

@@ -134,6 +134,32 @@ def test_batch_matches_single(oracle):
         compare_frame(kg, dg, ko, do)
 
 
+def test_batch_of_ten_narrow_distribution_form(oracle):
+    """Batches of more than 8 frames run the quadtree distribution with 256 threads per (frame, level), smaller
+    ones with 512: ten frames, some with so many candidates (white noise) that a level's candidates no longer
+    fit the threads' registers, must equal the oracle frame by frame, as the same frames do one by one."""
+    w, h, B = 1241, 376, 10
+    rng = np.random.default_rng(5)
+    imgs = []
+    for i in range(B):
+        if i % 3 == 1:
+            amp = 30 + 20 * i
+            imgs.append((128 + rng.integers(-amp, amp + 1, size=(h, w))).clip(0, 255).astype(np.uint8))
+        else:
+            imgs.append(orbx.synth_image(SEED + 17 * i, w, h, 0))
+    ex = make_extractor(KITTI, w, h, batch=B)
+    ex.extract_batch_host(imgs)
+    n, _ = ex.batch_counts()
+    one = make_extractor(KITTI, w, h)
+    for i in range(B):
+        kg, dg = ex.batch_download(i)
+        ko, do = oracle_extract(oracle, imgs[i], KITTI)
+        assert n[i] == len(ko)
+        compare_frame(kg, dg, ko, do)
+        k1, d1 = one(imgs[i])
+        assert np.array_equal(k1, kg) and np.array_equal(d1, dg)
+
+
 def test_padded_pyramid(oracle):
     img = orbx.synth_image(SEED, 320, 240, 0)
     ex = make_extractor(TUM, 320, 240)
