@@ -20,7 +20,9 @@ def load(d):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     files.sort(key=os.path.getmtime)  # a directory merged from several runs: the newest pass counts
     for r in csv.DictReader(open(files[-1])):
-        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # "void k_octree<256, 14>(...)" and "k_fast(...)" alike: the bare kernel name
+        name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return agg
 
 
