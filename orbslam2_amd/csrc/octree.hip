@@ -29,6 +29,10 @@ struct OctArgs {
     OctLevel lv[ORBX_MAX_LEVELS];
 };
 
+#ifndef OCT_STAMP
+#define OCT_STAMP(id)  // measurement hook of tools/exp_octree.hip
+#endif
+
 #define OCT_DROPPED 0xffffu  // node value of a candidate that the per-cell threshold fallback discards
 
 // 16 arrays of `cap` ints carved from dynamic LDS; addresses are computed, not stored, so that
@@ -49,9 +53,8 @@ struct OctLds {
     __device__ __forceinline__ int *spos() const { return base + 15 * cap; }   // new position of a surviving node
 };
 #define OCT_ARRAYS 16
-#define OCT_NT_MAX 512  // threads of the larger workgroup form
-#define OCT_WIDE_MAX_BATCH 8  // batches up to this many frames use it
-#define OCT_TAIL_INTS (OCT_NT_MAX / 64 + 4)  // wave sums of the block scan + the root count, behind the arrays
+#define OCT_NT 256  // threads of a workgroup (512 shorten nothing and cost a batch 10 % of its throughput)
+#define OCT_TAIL_INTS (OCT_NT / 64 + 4)  // wave sums of the block scan + the root count, behind the arrays
 
 size_t orbx_octree_lds_bytes(int node_cap) { return ((size_t)OCT_ARRAYS * node_cap + OCT_TAIL_INTS) * sizeof(int); }
 
@@ -126,6 +129,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         return;
     }
     const int N = quota;
+    OCT_STAMP(0);
 
     // ---- candidate storage ----
     constexpr int KR = KMAX > 0 ? KMAX : 1;
@@ -228,25 +232,48 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
     int cur = 0;
     bool last_kind = false;
     __syncthreads();
+    OCT_STAMP(1);
 
     for (int round = 0; round < 64; round++) {
         const int prev_size = size;
+        OCT_STAMP(2);
         int *bx = L.bx(cur), *by = L.by(cur), *cnt = L.cnt(cur), *seq = L.seq(cur);
         int *nbx = L.bx(cur ^ 1), *nby = L.by(cur ^ 1), *ncnt = L.cnt(cur ^ 1), *nseq = L.seq(cur ^ 1);
         const int per = (size + NT - 1) / NT;
         const int lo = min(tid * per, size), hi = min(lo + per, size);
 
         // ---- processing order of the nodes that hold more than one key ----
+        // In a round of the last kind the rank of a node is the number of nodes with a larger (count,
+        // creation index).  Both fit one word while counts stay below 2^18 (creation indices are below
+        // 4 * cap < 2^14): the words of all nodes are laid down first (in nzs, which this round fills later),
+        // so that the ranking loop is one broadcast LDS read and one compare per node, unrolled.
+        const bool packed_ok = n < (1 << 18);
         int my_e = 0;
         for (int i = lo; i < hi; i++) {
             my_e += cnt[i] >= 2;
             L.cc(0)[i] = L.cc(1)[i] = L.cc(2)[i] = L.cc(3)[i] = 0;
+            if (packed_ok)
+                L.nzs()[i] = cnt[i] >= 2 ? ((cnt[i] << 14) | seq[i]) : 0;
         }
         int m;
-        int ebase = block_excl_scan<NT>(my_e, wsum, &m);
+        int ebase = block_excl_scan<NT>(my_e, wsum, &m);  // its barriers also publish the packed words
+        // what kind of round this is (:716-723): m = the nodes the previous round left with more than one key
+        if (!last_kind && round > 0 && size + 3 * m > N)
+            last_kind = true;
+        const bool packed_rank = last_kind && packed_ok;
         if (!last_kind) {
             for (int i = lo; i < hi; i++)
                 L.prank()[i] = cnt[i] >= 2 ? ebase++ : -1;
+        } else if (packed_rank) {
+            const uint32_t *word = reinterpret_cast<const uint32_t *>(L.nzs());
+            for (int i = lo; i < hi; i++) {
+                const uint32_t wi = word[i];
+                int rk = 0;
+#pragma unroll 8
+                for (int j = 0; j < size; j++)
+                    rk += word[j] > wi;
+                L.prank()[i] = wi ? rk : -1;
+            }
         } else {
             for (int i = lo; i < hi; i++) {
                 int rk = -1;
@@ -266,10 +293,13 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             if (L.prank()[i] >= 0)
                 L.order()[L.prank()[i]] = i;
 
+        OCT_STAMP(3);
         // ---- key counts of the four children (:551-565) ----
+        uint32_t qpack = 0u;  // quadrant of candidate j in bits 2j, 2j+1 (register form)
         if constexpr (KMAX > 0) {
             // all reads first, then all atomics: the reads of different candidates overlap
             int enc[KR];
+            qpack = 0u;
 #pragma unroll
             for (int j = 0; j < KMAX; j++) {
                 const int k = tid + NT * j;
@@ -277,7 +307,9 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
                 const bool live = k < n && i != OCT_DROPPED;
                 const int ii = live ? i : 0;
                 const int c = cnt[ii], b_x = bx[ii], b_y = by[ii];
-                enc[j] = (live && c >= 2) ? (ii * 4 + quadrant_of(rxy[j], b_x, b_y)) : -1;
+                const int q = quadrant_of(rxy[j], b_x, b_y);
+                qpack |= (uint32_t)q << (2 * j);  // kept for the move at the end of the round
+                enc[j] = (live && c >= 2) ? (ii * 4 + q) : -1;
             }
 #pragma unroll
             for (int j = 0; j < KMAX; j++)
@@ -292,6 +324,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         }
         __syncthreads();
 
+        OCT_STAMP(4);
         // ---- how many nodes are processed: all, or up to the one that brings the list to N ----
         const int rper = (m + NT - 1) / NT;
         const int rlo = min(tid * rper, m), rhi = min(rlo + rper, m);
@@ -318,6 +351,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         __syncthreads();
         const int children = t > 0 ? L.nzs()[t - 1] : 0;
 
+        OCT_STAMP(5);
         // ---- survivors keep their relative order behind the new children ----
         int my_s = 0;
         for (int i = lo; i < hi; i++)
@@ -351,6 +385,9 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             const int c[4] = {L.cc(0)[i], L.cc(1)[i], L.cc(2)[i], L.cc(3)[i]};
             const int nz = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
             const int blk = children - L.nzs()[r];
+            // where this node's keys go: first child position and the mask of non-empty children
+            L.spos()[i] = (int)(0x80000000u | ((uint32_t)blk << 4) | (uint32_t)((c[0] > 0) | ((c[1] > 0) << 1) |
+                                                                             ((c[2] > 0) << 2) | ((c[3] > 0) << 3)));
             int before = 0;
             for (int q = 0; q < 4; q++) {
                 if (c[q] == 0)
@@ -364,44 +401,37 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             }
         }
         __syncthreads();
+        OCT_STAMP(6);
         // ---- move the keys to their new node ----
         for_keys([&](int j, int k) {
             const int i = NODE(j, k);
             if (i == OCT_DROPPED)
                 return;
-            // branch-free: every operand is read, the result is selected
-            const int r = L.prank()[i];
-            const bool moved = r >= 0 && r < t;
-            const int q = quadrant_of(XY(j, k), bx[i], by[i]);
-            const int c0 = L.cc(0)[i] > 0, c1 = L.cc(1)[i] > 0, c2 = L.cc(2)[i] > 0, c3 = L.cc(3)[i] > 0;
-            const int nz = c0 + c1 + c2 + c3;
-            const int before = (q > 0 ? c0 : 0) + (q > 1 ? c1 : 0) + (q > 2 ? c2 : 0);
-            const int child = children - L.nzs()[moved ? r : 0] + (nz - 1 - before);
-            SET_NODE(j, k, moved ? child : L.spos()[i]);
+            // one word per node: a survivor's new position, or (bit 31) the block of a processed node's
+            // children, pushed to the front one after the other, so the last non-empty child comes first
+            const uint32_t d = (uint32_t)L.spos()[i];
+            int q;
+            if constexpr (KMAX > 0)
+                q = (int)((qpack >> (2 * j)) & 3u);
+            else
+                q = (d & 0x80000000u) ? quadrant_of(XY(j, k), bx[i], by[i]) : 0;
+            const uint32_t mask = d & 15u;
+            const int child = (int)((d >> 4) & 0x07ffffffu) + __popc(mask) - 1 - __popc(mask & ((1u << q) - 1u));
+            SET_NODE(j, k, (d & 0x80000000u) ? child : (int)d);
         });
         __syncthreads();
         size = new_size;
         cur ^= 1;
 
-        // ---- what comes next (:716-723, :784-785) ----
+        OCT_STAMP(7);
+        // ---- finished (:716-718, :784-785)?  The kind of the next round is decided at its start ----
         if (size >= N || size == prev_size)
             break;
-        if (!last_kind) {
-            int my_x = 0;
-            const int per2 = (size + NT - 1) / NT;
-            const int lo2 = min(tid * per2, size), hi2 = min(lo2 + per2, size);
-            for (int i = lo2; i < hi2; i++)
-                my_x += L.cnt(cur)[i] >= 2;
-            int n_expand;
-            block_excl_scan<NT>(my_x, wsum, &n_expand);
-            if (size + 3 * n_expand > N)
-                last_kind = true;
-        }
-        __syncthreads();
     }
 
     // ---- best key of every node (:791-810): largest response, first in candidate order ----
     __syncthreads();
+    OCT_STAMP(8);
     unsigned long long *best = reinterpret_cast<unsigned long long *>(L.cc(0));  // cc[0],cc[1] are adjacent
     for (int i = tid; i < size; i += NT)
         best[i] = 0ull;
@@ -426,14 +456,16 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
                 out_idx[i] = (int)k;
         }
     });
+    OCT_STAMP(9);
     if (tid == 0)
         *out_n = size;
 }
 
-// Candidates per thread held in registers: 16 in the wide form (levels with up to 8192 candidates), 14 in the
-// narrow form (3584; measured: 12, 14 and 16 give the same batch throughput, 14 the shortest kernel).
-#define OCT_KMAX_WIDE 16
-#define OCT_KMAX_NARROW 14
+// Candidates per thread held in registers (levels with up to 256 * OCT_KMAX candidates; beyond that they stay
+// in global memory)
+#ifndef OCT_KMAX
+#define OCT_KMAX 16
+#endif
 
 template <int NT, int KMAX, typename... Args> __device__ __forceinline__ void octree_dispatch(int n, Args... args)
 {
@@ -481,13 +513,6 @@ hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream
     }
     // every level carves its own node_cap out of an allocation sized for the largest level
     const size_t lds = orbx_octree_lds_bytes(cap);
-    // Few frames: a level's candidates spread over 512 threads (the chain of rounds is the latency of a
-    // single call).  Many frames: 256 threads, so that more workgroups of other kernels fit beside these.
-    static const int forced = [] {
-        const char *e = getenv("ORBX_OCTREE_THREADS");
-        return e ? atoi(e) : 0;
-    }();
-    const bool wide = forced ? forced >= 512 : g.batch <= OCT_WIDE_MAX_BATCH;
     auto launch = [&](auto kernel, int nt) -> hipError_t {
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -499,7 +524,7 @@ hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream
                                                          b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status, a);
         return hipGetLastError();
     };
-    return wide ? launch(k_octree<OCT_NT_MAX, OCT_KMAX_WIDE>, OCT_NT_MAX) : launch(k_octree<256, OCT_KMAX_NARROW>, 256);
+    return launch(k_octree<OCT_NT, OCT_KMAX>, OCT_NT);
 }
 
 template <int NT>
@@ -508,7 +533,7 @@ __global__ __launch_bounds__(NT) void k_octree_single(const uint32_t *xy, const 
                                                        uint32_t *out_xy, uint8_t *out_resp, int *out_idx, int *out_n,
                                                        int *status)
 {
-    octree_dispatch<NT, OCT_KMAX_WIDE>(n, xy, resp, (const uint32_t *)nullptr, (const uint8_t *)nullptr, 0, 0, node, n, quota, n_ini, hx,
+    octree_dispatch<NT, OCT_KMAX>(n, xy, resp, (const uint32_t *)nullptr, (const uint8_t *)nullptr, 0, 0, node, n, quota, n_ini, hx,
                     region_h, cap, 0, out_xy, out_resp, out_idx, out_n, status);
 }
 
@@ -520,12 +545,12 @@ hipError_t orbx_launch_octree_single(const uint32_t *d_xy, const uint8_t *d_resp
     const float hx = (float)region_w / (float)n_ini;
     const size_t lds = orbx_octree_lds_bytes(node_cap);
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree_single<OCT_NT_MAX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree_single<OCT_NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess)
             return e;
     }
-    k_octree_single<OCT_NT_MAX><<<1, OCT_NT_MAX, lds, s>>>(d_xy, d_resp, d_node, n, quota, n_ini, hx, region_h, node_cap,
+    k_octree_single<OCT_NT><<<1, OCT_NT, lds, s>>>(d_xy, d_resp, d_node, n, quota, n_ini, hx, region_h, node_cap,
                                                            d_out_xy, d_out_resp, d_out_idx, d_nout, d_status);
     return hipGetLastError();
 }

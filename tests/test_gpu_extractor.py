@@ -134,10 +134,10 @@ def test_batch_matches_single(oracle):
         compare_frame(kg, dg, ko, do)
 
 
-def test_batch_of_ten_narrow_distribution_form(oracle):
-    """Batches of more than 8 frames run the quadtree distribution with 256 threads per (frame, level), smaller
-    ones with 512: ten frames, some with so many candidates (white noise) that a level's candidates no longer
-    fit the threads' registers, must equal the oracle frame by frame, as the same frames do one by one."""
+def test_batch_of_ten_with_crowded_levels(oracle):
+    """Ten frames in one batch, some with so many candidates (white noise) that a level's candidates no longer
+    fit the registers of the distribution kernel's threads: each must equal the oracle, and the same frame
+    extracted alone."""
     w, h, B = 1241, 376, 10
     rng = np.random.default_rng(5)
     imgs = []
