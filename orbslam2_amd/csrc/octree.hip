@@ -54,35 +54,29 @@ struct OctLds {
 };
 #define OCT_ARRAYS 16
 #define OCT_NT 256  // threads of a workgroup (512 shorten nothing and cost a batch 10 % of its throughput)
-#define OCT_TAIL_INTS (OCT_NT / 64 + 4)  // wave sums of the block scan + the root count, behind the arrays
+#define OCT_TAIL_INTS (2 * (OCT_NT / 64) + 4)  // two sets of wave sums of the block scan + the root count, behind the arrays
 
 size_t orbx_octree_lds_bytes(int node_cap) { return ((size_t)OCT_ARRAYS * node_cap + OCT_TAIL_INTS) * sizeof(int); }
 
-__device__ __forceinline__ int wave_incl_scan(int v)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d, 64);
-        if ((int)(threadIdx.x & 63) >= d)
-            v += t;
-    }
-    return v;
-}
+extern "C" __device__ int __ockl_wfscan_add_i32(int, bool);  // wave-wide prefix sum (device library, DPP)
 
-// exclusive prefix of one value per thread over the workgroup; *total = its sum
+// Exclusive prefix of one value per thread over the workgroup; *total = its sum.  wsum holds two sets of
+// NT/64 wave sums used in turn (`phase` counts the calls, uniformly): a set is rewritten only after every
+// thread has passed the barrier of the call in between, so one barrier per call is enough.
 template <int NT>
-__device__ __forceinline__ int block_excl_scan(int v, int *wsum /* NT/64 ints of LDS */, int *total)
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &phase, int *total)
 {
-    const int inc = wave_incl_scan(v);
+    const int inc = __ockl_wfscan_add_i32(v, true);
     const int wv = threadIdx.x >> 6;
-    __syncthreads();  // wsum may still be read from a previous call
+    int *ws = wsum + (phase & 1) * (NT / 64);
+    phase++;
     if ((threadIdx.x & 63) == 63)
-        wsum[wv] = inc;
+        ws[wv] = inc;
     __syncthreads();
     int base = 0, all = 0;
 #pragma unroll
     for (int i = 0; i < NT / 64; i++) {
-        const int w = wsum[i];
+        const int w = ws[i];
         base += i < wv ? w : 0;
         all += w;
     }
@@ -120,7 +114,8 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
     // all LDS lives in the one dynamic array, so its base alignment is not disturbed
     extern __shared__ __attribute__((aligned(16))) int lds[];
     int *wsum = lds + (size_t)OCT_ARRAYS * cap;
-    int &sh_size = wsum[NT / 64];
+    int &sh_size = wsum[2 * (NT / 64)];
+    int phase = 0;  // calls of block_excl_scan so far
     const OctLds L{lds, cap};
     const int tid = threadIdx.x;
     if (n <= 0) {
@@ -136,13 +131,17 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
     uint32_t rxy[KR];
     int rnode[KR];
     unsigned long long rbk[KR];  // response<<32 | ~order key: the maximum is the node's keeper
+    // Register form: a thread holds consecutive candidates.  Neighbours in the list are neighbours in the image
+    // (the list is cell-major), so they mostly share their node and quadrant, and a thread's LDS atomics
+    // collapse into one per run of equal targets.
+    const int kper = (n + NT - 1) / NT, kbase = tid * kper;
+    const int nmine = max(0, min(kper, n - kbase));
     auto for_keys = [&](auto fn) {
         if constexpr (KMAX > 0) {
 #pragma unroll
             for (int j = 0; j < KMAX; j++) {
-                const int k = tid + NT * j;
-                if (k < n)
-                    fn(j, k);
+                if (j < nmine)
+                    fn(j, kbase + j);
             }
         } else {
             for (int k = tid; k < n; k += NT)
@@ -180,10 +179,12 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         uint32_t rk[KR];
 #pragma unroll
         for (int j = 0; j < KMAX; j++) {
-            const int k = tid + NT * j;
-            rxy[j] = k < n ? xy[k] : 0u;
-            rr[j] = k < n ? resp[k] : (uint8_t)0;
-            rk[j] = (k < n && key) ? key[k] : (uint32_t)k;
+            const int k = kbase + j;
+            const bool have = j < nmine;
+            rxy[j] = have ? xy[k] : 0u;
+            rr[j] = have ? resp[k] : (uint8_t)0;
+            rk[j] = (have && key) ? key[k] : (uint32_t)k;
+            rnode[j] = OCT_DROPPED;  // slots without a candidate stay dropped
         }
 #pragma unroll
         for (int j = 0; j < KMAX; j++)
@@ -203,8 +204,23 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         int r = (int)((float)(XY(j, k) & 0xffff) / hx);
         r = r < n_ini ? r : n_ini - 1;
         SET_NODE(j, k, r);
-        atomicAdd(&L.cnt(1)[r], 1);
+        if constexpr (KMAX == 0)
+            atomicAdd(&L.cnt(1)[r], 1);
     });
+    if constexpr (KMAX > 0) {
+        int run = OCT_DROPPED, len = 0;
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) {
+            if (rnode[j] != run) {
+                if (run != OCT_DROPPED)
+                    atomicAdd(&L.cnt(1)[run], len);
+                run = rnode[j], len = 0;
+            }
+            len++;
+        }
+        if (run != OCT_DROPPED)
+            atomicAdd(&L.cnt(1)[run], len);
+    }
     __syncthreads();
     if (tid == 0) {
         int s = 0;
@@ -255,8 +271,10 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             if (packed_ok)
                 L.nzs()[i] = cnt[i] >= 2 ? ((cnt[i] << 14) | seq[i]) : 0;
         }
+        if (packed_ok && tid < 3 && size + tid < ((size + 3) & ~3))
+            L.nzs()[size + tid] = 0;  // padding of the last group of four
         int m;
-        int ebase = block_excl_scan<NT>(my_e, wsum, &m);  // its barriers also publish the packed words
+        int ebase = block_excl_scan<NT>(my_e, wsum, phase, &m);  // its barriers also publish the packed words
         // what kind of round this is (:716-723): m = the nodes the previous round left with more than one key
         if (!last_kind && round > 0 && size + 3 * m > N)
             last_kind = true;
@@ -265,13 +283,19 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             for (int i = lo; i < hi; i++)
                 L.prank()[i] = cnt[i] >= 2 ? ebase++ : -1;
         } else if (packed_rank) {
+            // four words per LDS read (cap is a multiple of 4 and the arrays start 16-byte aligned; the words
+            // behind the list's end were cleared above)
             const uint32_t *word = reinterpret_cast<const uint32_t *>(L.nzs());
+            const uint4 *word4 = reinterpret_cast<const uint4 *>(L.nzs());
+            const int size4 = (size + 3) >> 2;
             for (int i = lo; i < hi; i++) {
                 const uint32_t wi = word[i];
                 int rk = 0;
-#pragma unroll 8
-                for (int j = 0; j < size; j++)
-                    rk += word[j] > wi;
+#pragma unroll 4
+                for (int j = 0; j < size4; j++) {
+                    const uint4 w = word4[j];
+                    rk += (w.x > wi) + (w.y > wi) + (w.z > wi) + (w.w > wi);
+                }
                 L.prank()[i] = wi ? rk : -1;
             }
         } else {
@@ -302,19 +326,26 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             qpack = 0u;
 #pragma unroll
             for (int j = 0; j < KMAX; j++) {
-                const int k = tid + NT * j;
                 const int i = rnode[j];
-                const bool live = k < n && i != OCT_DROPPED;
+                const bool live = i != OCT_DROPPED;
                 const int ii = live ? i : 0;
                 const int c = cnt[ii], b_x = bx[ii], b_y = by[ii];
                 const int q = quadrant_of(rxy[j], b_x, b_y);
                 qpack |= (uint32_t)q << (2 * j);  // kept for the move at the end of the round
                 enc[j] = (live && c >= 2) ? (ii * 4 + q) : -1;
             }
+            int run = -1, len = 0;
 #pragma unroll
-            for (int j = 0; j < KMAX; j++)
-                if (enc[j] >= 0)
-                    atomicAdd(&L.cc(enc[j] & 3)[enc[j] >> 2], 1);
+            for (int j = 0; j < KMAX; j++) {
+                if (enc[j] != run) {
+                    if (run >= 0)
+                        atomicAdd(&L.cc(run & 3)[run >> 2], len);
+                    run = enc[j], len = 0;
+                }
+                len++;
+            }
+            if (run >= 0)
+                atomicAdd(&L.cc(run & 3)[run >> 2], len);
         } else {
             for_keys([&](int j, int k) {
                 const int i = NODE(j, k);
@@ -334,7 +365,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
             my_nz += (L.cc(0)[i] > 0) + (L.cc(1)[i] > 0) + (L.cc(2)[i] > 0) + (L.cc(3)[i] > 0);
         }
         int nz_total;
-        int run = block_excl_scan<NT>(my_nz, wsum, &nz_total);
+        int run = block_excl_scan<NT>(my_nz, wsum, phase, &nz_total);
         int below = 0;  // processed nodes after which the list is still shorter than N
         for (int r = rlo; r < rhi; r++) {
             const int i = L.order()[r];
@@ -345,7 +376,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         int t = m;
         if (last_kind) {
             int t0;
-            block_excl_scan<NT>(below, wsum, &t0);
+            block_excl_scan<NT>(below, wsum, phase, &t0);
             t = min(t0 + 1, m);
         }
         __syncthreads();
@@ -357,7 +388,7 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         for (int i = lo; i < hi; i++)
             my_s += !(L.prank()[i] >= 0 && L.prank()[i] < t);
         int nsurv;
-        int sbase = block_excl_scan<NT>(my_s, wsum, &nsurv);
+        int sbase = block_excl_scan<NT>(my_s, wsum, phase, &nsurv);
         const int new_size = children + nsurv;
         if (new_size > cap) {
             // cannot happen for a correctly sized list; reported instead of writing out of bounds
@@ -403,22 +434,30 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
         __syncthreads();
         OCT_STAMP(6);
         // ---- move the keys to their new node ----
-        for_keys([&](int j, int k) {
-            const int i = NODE(j, k);
-            if (i == OCT_DROPPED)
-                return;
-            // one word per node: a survivor's new position, or (bit 31) the block of a processed node's
-            // children, pushed to the front one after the other, so the last non-empty child comes first
-            const uint32_t d = (uint32_t)L.spos()[i];
-            int q;
-            if constexpr (KMAX > 0)
-                q = (int)((qpack >> (2 * j)) & 3u);
-            else
-                q = (d & 0x80000000u) ? quadrant_of(XY(j, k), bx[i], by[i]) : 0;
+        // one word per node: a survivor's new position, or (bit 31) the block of a processed node's
+        // children, pushed to the front one after the other, so the last non-empty child comes first
+        auto destination = [](uint32_t d, int q) -> int {
             const uint32_t mask = d & 15u;
             const int child = (int)((d >> 4) & 0x07ffffffu) + __popc(mask) - 1 - __popc(mask & ((1u << q) - 1u));
-            SET_NODE(j, k, (d & 0x80000000u) ? child : (int)d);
-        });
+            return (d & 0x80000000u) ? child : (int)d;
+        };
+        if constexpr (KMAX > 0) {
+            uint32_t d[KR];
+#pragma unroll
+            for (int j = 0; j < KMAX; j++)
+                d[j] = (uint32_t)L.spos()[rnode[j] != OCT_DROPPED ? rnode[j] : 0];
+#pragma unroll
+            for (int j = 0; j < KMAX; j++)
+                rnode[j] = rnode[j] != OCT_DROPPED ? destination(d[j], (int)((qpack >> (2 * j)) & 3u)) : OCT_DROPPED;
+        } else {
+            for_keys([&](int j, int k) {
+                const int i = NODE(j, k);
+                if (i == OCT_DROPPED)
+                    return;
+                const uint32_t d = (uint32_t)L.spos()[i];
+                SET_NODE(j, k, destination(d, (d & 0x80000000u) ? quadrant_of(XY(j, k), bx[i], by[i]) : 0));
+            });
+        }
         __syncthreads();
         size = new_size;
         cur ^= 1;
@@ -436,11 +475,27 @@ __device__ __forceinline__ void octree_body(const uint32_t *__restrict__ xy, con
     for (int i = tid; i < size; i += NT)
         best[i] = 0ull;
     __syncthreads();
-    for_keys([&](int j, int k) {
-        const int i = NODE(j, k);
-        if (i != OCT_DROPPED)
-            atomicMax(&best[i], BK(j, k));
-    });
+    if constexpr (KMAX > 0) {
+        int run = OCT_DROPPED;
+        unsigned long long top = 0ull;
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) {
+            if (rnode[j] != run) {
+                if (run != OCT_DROPPED)
+                    atomicMax(&best[run], top);
+                run = rnode[j], top = 0ull;
+            }
+            top = rbk[j] > top ? rbk[j] : top;
+        }
+        if (run != OCT_DROPPED)
+            atomicMax(&best[run], top);
+    } else {
+        for_keys([&](int j, int k) {
+            const int i = NODE(j, k);
+            if (i != OCT_DROPPED)
+                atomicMax(&best[i], BK(j, k));
+        });
+    }
     __syncthreads();
     // the winner of a node is the one candidate whose (response, order key) equals the maximum
     for_keys([&](int j, int k) {

@@ -190,7 +190,7 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
                 return ORBX_E_GEOMETRY;
             L.hx = width / L.n_ini;
         }
-        L.node_cap = std::max(L.quota, 4 * L.n_ini) + 4;
+        L.node_cap = align_up(std::max(L.quota, 4 * L.n_ini) + 4, 4);  // a multiple of 4: 16-byte LDS reads of node words
         if (orbx_octree_lds_bytes(L.node_cap) > 160 * 1024)
             return ORBX_E_ARG;  // the node list of one level must fit the LDS of a compute unit
         L.kp_base = kps;
@@ -789,7 +789,7 @@ extern "C" int orbx_batch_download_all(orbx_extractor *ex, orbx_keypoint *keypoi
         }
         HIP_TRY(hipStreamSynchronize(ex->stream));
     } else {
-        const size_t need = (kp_row + de_row) * (size_t)ex->p.max_batch;
+        const size_t need = (kp_row + de_row) * (size_t)ex->p.max_batch + 256;  // + the header orbx_extract keeps there
         if (ex->h_out_bytes < need) {
             if (ex->h_out)
                 HIP_TRY(hipHostFree(ex->h_out));
@@ -852,10 +852,42 @@ extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width,
     int rc = orbx_extract_batch_host(ex, one, 1, width, height, stride_bytes);
     if (rc != ORBX_OK)
         return rc;
-    rc = orbx_batch_counts(ex, nullptr, nullptr);
-    if (rc != ORBX_OK)
-        return rc;
-    return orbx_batch_download(ex, 0, keypoints, descriptors, cap, n_out);
+    // One round trip for everything: count, status and the frame's whole result rows go to page-locked
+    // staging with asynchronous copies behind the kernels, then one wait.  (Asking for the count first and
+    // copying exactly that many rows afterwards costs two more waits than the 150 KB of spare rows cost.)
+    const size_t oc = (size_t)ex->geom.out_cap;
+    const size_t kp_bytes = oc * sizeof(orbx_keypoint), de_bytes = oc * 32, head_bytes = 256;
+    const size_t need = (kp_bytes + de_bytes) * (size_t)ex->p.max_batch + head_bytes;
+    if (ex->h_out_bytes < need) {
+        if (ex->h_out)
+            HIP_TRY(hipHostFree(ex->h_out));
+        ex->h_out = nullptr;
+        ex->h_out_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&ex->h_out, need, hipHostMallocDefault));
+        ex->h_out_bytes = need;
+    }
+    // the header sits behind the rows of a whole batch, which orbx_batch_download_all stages in the same buffer
+    int *head = reinterpret_cast<int *>(ex->h_out + (kp_bytes + de_bytes) * (size_t)ex->p.max_batch);
+    static_assert((1 + ORBX_ST_COUNT) * sizeof(int) <= 256, "header of the staging buffer");
+    uint8_t *h_kp = ex->h_out, *h_de = ex->h_out + kp_bytes;
+    HIP_TRY(hipMemcpyAsync(head, ex->buf.out_n, sizeof(int), hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipMemcpyAsync(head + 1, ex->buf.status, sizeof(int) * ORBX_ST_COUNT, hipMemcpyDeviceToHost, ex->stream));
+    if (keypoints)
+        HIP_TRY(hipMemcpyAsync(h_kp, ex->buf.out_kp, kp_bytes, hipMemcpyDeviceToHost, ex->stream));
+    if (descriptors)
+        HIP_TRY(hipMemcpyAsync(h_de, ex->buf.out_desc, de_bytes, hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    if (head[1 + ORBX_ST_CAND_OVERFLOW] || head[1 + ORBX_ST_NODE_OVERFLOW])
+        return ORBX_E_CAPACITY;
+    const int n = head[0];
+    *n_out = n;
+    if (n > cap)
+        return ORBX_E_CAPACITY;
+    if (n > 0 && keypoints)
+        memcpy(keypoints, h_kp, (size_t)n * sizeof(orbx_keypoint));
+    if (n > 0 && descriptors)
+        memcpy(descriptors, h_de, (size_t)n * 32);
+    return ORBX_OK;
 }
 
 static inline int reflect101(int i, int n)
@@ -989,7 +1021,7 @@ extern "C" int orbx_debug_octree(int device, const int *xs, const int *ys, const
     const int n_ini = (int)roundf((float)region_w / (float)region_h);
     if (n_ini < 1)
         return ORBX_E_GEOMETRY;
-    const int node_cap = std::max(quota, 4 * n_ini) + 4;
+    const int node_cap = align_up(std::max(quota, 4 * n_ini) + 4, 4);
     if (orbx_octree_lds_bytes(node_cap) > 160 * 1024)
         return ORBX_E_ARG;
     HIP_TRY(hipSetDevice(device));

@@ -35,7 +35,7 @@ struct OrbxLevel {
     int quota;       // mnFeaturesPerLevel[level]
     int n_ini;       // quadtree roots
     float hx;        // root width
-    int node_cap;    // capacity of the node list of the level (max(quota, 4*n_ini) + 4)
+    int node_cap;    // capacity of the node list of the level (max(quota, 4*n_ini) + 4, rounded up to a multiple of 4)
     int kp_base;     // segment of the per-frame kept-keypoint arrays
     float scale;     // mvScaleFactor[level]
     int patch_size;  // (int)(31*scale)

@@ -6,6 +6,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 __device__ unsigned long long g_stamp[512];
@@ -34,7 +35,7 @@ template <int NT> static int run(int n, int quota, const std::vector<uint32_t> &
     const int rw = 1209, rh = 344;
     const int n_ini = (int)roundf((float)rw / rh);
     const float hx = (float)rw / n_ini;
-    const int cap = (quota > 4 * n_ini ? quota : 4 * n_ini) + 4;
+    const int cap = ((quota > 4 * n_ini ? quota : 4 * n_ini) + 4 + 3) & ~3;
     uint32_t *d_xy, *d_oxy;
     uint8_t *d_rp, *d_orp;
     uint16_t *d_node;
@@ -102,5 +103,18 @@ int main(int argc, char **argv)
         rp[i] = (uint8_t)(7 + (s >> 50) % 60);
         i++;
     }
-    return run<256>(n, quota, xy, rp);
+    // the order of the library's candidate lists: by 30-pixel cell, row-major inside a cell
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; i++)
+        idx[i] = i;
+    auto cell_key = [&](int i) {
+        const unsigned x = xy[i] & 0xffff, y = xy[i] >> 16;
+        return ((unsigned long long)((y / 30) * 64 + x / 30) << 32) | (y << 16) | x;
+    };
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return cell_key(a) < cell_key(b); });
+    std::vector<uint32_t> sxy(n);
+    std::vector<uint8_t> srp(n);
+    for (int i = 0; i < n; i++)
+        sxy[i] = xy[idx[i]], srp[i] = rp[idx[i]];
+    return run<256>(n, quota, sxy, srp);
 }
