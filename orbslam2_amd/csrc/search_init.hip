@@ -32,7 +32,7 @@ struct SfiArgs {
 // bytes of dynamic LDS for `cap0` level-0 keypoints per frame
 size_t orbx_search_init_lds_bytes(int cap0)
 {
-    return (size_t)cap0 * (SFI_DSTRIDE * 4 + 4 * 7 + 2 * 6 + 4);
+    return (size_t)cap0 * (SFI_DSTRIDE * 4 + 4 * 7 + 2 * 6 + 4 + 32);
 }
 
 __device__ __forceinline__ int lanes_below64(unsigned long long m)
@@ -40,7 +40,9 @@ __device__ __forceinline__ int lanes_below64(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-__global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restrict__ kp,
+#define SFI_NT 256  // threads that prepare a pair; the first wave then walks it alone
+
+__global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__restrict__ kp,
                                                     const uint8_t *__restrict__ desc, const int *__restrict__ counts,
                                                     const float *__restrict__ prev_in, float *__restrict__ prev_out,
                                                     int *__restrict__ matches12, int *__restrict__ nmatches,
@@ -65,24 +67,31 @@ __global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restr
     uint16_t *idx1 = m21 + cap;                                  // index in frame 1's keypoint array
     uint16_t *m12 = idx1 + cap;                                  // vnMatches12 as position in frame 2's list
     uint8_t *bin1 = reinterpret_cast<uint8_t *>(m12 + cap);      // rotation bin of an accepted match, 0xff: none
+    // descriptors of frame 1's level-0 keypoints in list order: a query read from global memory would set the
+    // pace of the walk (one memory latency per step)
+    uint32_t *d1 = reinterpret_cast<uint32_t *>(bin1 + cap);     // cap * 8 dwords (cap is a multiple of 4)
     __shared__ int hist[32];
     __shared__ int colstart[SFI_COLS + 1];  // first sorted position of each cell column
+    __shared__ int s_wc[2][2][SFI_NT / 64];  // per chunk parity and frame: the waves' counts
 
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n1 = min(counts[p], a.max_kp), n2 = min(counts[p + 1], a.max_kp);
     const orbx_keypoint *k1 = kp + (size_t)p * a.max_kp, *k2 = kp + (size_t)(p + 1) * a.max_kp;
     const uint32_t *dsc1 = reinterpret_cast<const uint32_t *>(desc) + (size_t)p * a.max_kp * 8;
     const uint32_t *dsc2 = reinterpret_cast<const uint32_t *>(desc) + (size_t)(p + 1) * a.max_kp * 8;
     int *out12 = matches12 + (size_t)p * a.max_kp;
-    for (int i = lane; i < a.max_kp; i += 64)
+    for (int i = tid; i < a.max_kp; i += SFI_NT)
         out12[i] = -1;
-    if (lane < 32)
-        hist[lane] = 0;
+    if (tid < 32)
+        hist[tid] = 0;
 
-    // ---- level-0 keypoints of frame 2 that lie in a grid cell: sort keys, in keypoint order ----
+    // ---- set-up by the whole workgroup ----
+    // level-0 keypoints of frame 2 that lie in a grid cell (sort keys) and level-0 keypoints of frame 1, both
+    // compacted in keypoint order: 256 keypoints of either frame per step, positions from the waves' ballots
     int n20 = 0, n10 = 0;
-    for (int i0 = 0; i0 < n2; i0 += 64) {
-        const int i = i0 + lane;
+    const int nmax = max(n1, n2);
+    for (int i0 = 0, par = 0; i0 < nmax; i0 += SFI_NT, par ^= 1) {
+        const int i = i0 + tid;
         int cell = SFI_NONE;
         if (i < n2 && k2[i].octave == 0) {
             // Frame::PosInGrid: rounded cell; keypoints outside the grid are in no cell
@@ -90,41 +99,58 @@ __global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restr
             if (px >= 0 && px < SFI_COLS && py >= 0 && py < SFI_ROWS)
                 cell = (px << 8) | py;
         }
-        const unsigned long long bm = __ballot(cell != (int)SFI_NONE);
-        const int pos = n20 + lanes_below64(bm);
-        if (cell != (int)SFI_NONE && pos < cap)
-            skey[pos] = ((uint32_t)cell << 16) | (uint32_t)i;
-        n20 += __popcll(bm);
-    }
-    for (int i0 = 0; i0 < n1; i0 += 64) {
-        const int i = i0 + lane;
         const bool lvl0 = i < n1 && k1[i].octave <= 0;  // the reference skips octave > 0
-        const unsigned long long bm = __ballot(lvl0);
-        const int pos = n10 + lanes_below64(bm);
-        if (lvl0 && pos < cap) {
+        float fx = 0.f, fy = 0.f, fa = 0.f;
+        if (lvl0) {
             const size_t pi = ((size_t)p * a.max_kp + i) * 2;
-            x1[pos] = prev_in ? prev_in[pi] : k1[i].x;
-            y1[pos] = prev_in ? prev_in[pi + 1] : k1[i].y;
-            ang1[pos] = k1[i].angle;
-            idx1[pos] = (uint16_t)i;
-            m12[pos] = (uint16_t)SFI_NONE;
-            bin1[pos] = 0xff;
+            fx = prev_in ? prev_in[pi] : k1[i].x;
+            fy = prev_in ? prev_in[pi + 1] : k1[i].y;
+            fa = k1[i].angle;
         }
-        n10 += __popcll(bm);
+        const unsigned long long bm2 = __ballot(cell != (int)SFI_NONE), bm1 = __ballot(lvl0);
+        if (lane == 0)
+            s_wc[par][0][wv] = __popcll(bm2), s_wc[par][1][wv] = __popcll(bm1);
+        __syncthreads();  // one barrier per step: the counts of the step before live in the other half
+        int before2 = 0, before1 = 0, all2 = 0, all1 = 0;
+#pragma unroll
+        for (int k = 0; k < SFI_NT / 64; k++) {
+            const int c2 = s_wc[par][0][k], c1 = s_wc[par][1][k];
+            before2 += k < wv ? c2 : 0, before1 += k < wv ? c1 : 0;
+            all2 += c2, all1 += c1;
+        }
+        const int pos2 = n20 + before2 + lanes_below64(bm2), pos1 = n10 + before1 + lanes_below64(bm1);
+        if (cell != (int)SFI_NONE && pos2 < cap)
+            skey[pos2] = ((uint32_t)cell << 16) | (uint32_t)i;
+        if (lvl0 && pos1 < cap) {
+            x1[pos1] = fx, y1[pos1] = fy, ang1[pos1] = fa;
+            idx1[pos1] = (uint16_t)i;
+            m12[pos1] = (uint16_t)SFI_NONE;
+            bin1[pos1] = 0xff;
+        }
+        n20 += all2, n10 += all1;
     }
     if (n10 > cap || n20 > cap) {  // more level-0 keypoints than the caller allowed for
-        if (lane == 0)
+        if (tid == 0)
             nmatches[p] = ORBX_E_CAPACITY, pair_count[p] = 0;
         return;
     }
+    if (tid < 3 && n20 + tid < ((n20 + 3) & ~3))
+        skey[n20 + tid] = 0xffffffffu;  // padding of the last group of four keys (cap is a multiple of 4)
     __syncthreads();
+    for (int e = tid; e < n10 * 8; e += SFI_NT)
+        d1[e] = dsc1[(size_t)idx1[e >> 3] * 8 + (e & 7)];
     // ---- rank sort (keys are distinct), then everything of frame 2 goes to its sorted position ----
-    for (int e0 = 0; e0 < n20; e0 += 64) {
-        const int e = e0 + lane;
+    const uint4 *skey4 = reinterpret_cast<const uint4 *>(skey);
+    const int n204 = (n20 + 3) >> 2;
+    for (int e0 = 0; e0 < n20; e0 += SFI_NT) {
+        const int e = e0 + tid;
         const uint32_t mine = e < n20 ? skey[e] : 0xffffffffu;
         int rank = 0;
-        for (int q = 0; q < n20; q++)
-            rank += skey[q] < mine;  // the same address in every lane
+#pragma unroll 4
+        for (int q = 0; q < n204; q++) {  // the same address in every lane
+            const uint4 k4 = skey4[q];
+            rank += (k4.x < mine) + (k4.y < mine) + (k4.z < mine) + (k4.w < mine);
+        }
         if (e < n20) {
             const int i = mine & 0xffffu;
             x2[rank] = k2[i].x, y2[rank] = k2[i].y, ang2[rank] = k2[i].angle;
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restr
     }
     __syncthreads();
     // colstart[c] = number of sorted entries in cell columns below c
-    for (int c = lane; c <= SFI_COLS; c += 64) {
+    for (int c = tid; c <= SFI_COLS; c += SFI_NT) {
         int lo = 0, hi = n20;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -151,6 +177,12 @@ __global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restr
         colstart[c] = lo;
     }
     __syncthreads();
+    // The walk is sequential: the first wave does it alone.  From here on there is no workgroup barrier (the
+    // other waves are gone); inside one wave LDS operations complete in program order, so a write by lane 0 is
+    // seen by the reads of all lanes that follow it once the compiler keeps that order (wave_sync below).
+    if (wv != 0)
+        return;
+    auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
 
     // ---- the order-dependent pass (:446-516) ----
     int npairs = 0;
@@ -160,10 +192,9 @@ __global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restr
     auto fetch_query = [&](int j) {
         if (j < n10) {
             nqx = x1[j], nqy = y1[j];
-            const int i1 = __builtin_amdgcn_readfirstlane((int)idx1[j]);
 #pragma unroll
             for (int k = 0; k < 8; k++)
-                nq[k] = dsc1[(size_t)i1 * 8 + k];  // the same address in every lane: scalar loads
+                nq[k] = d1[j * 8 + k];  // the same address in every lane: LDS broadcasts
         }
     };
     fetch_query(0);
@@ -229,10 +260,10 @@ __global__ __launch_bounds__(64) void k_search_init(const orbx_keypoint *__restr
                     hist[bin & 31]++;
                 }
             }
-            __syncthreads();  // lane 0's updates are read by every lane from here on
+            wave_sync();  // lane 0's updates are read by every lane from here on
         }
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- rotation consistency (:502-541, ComputeThreeMaxima :1698-1739) ----
     int i1m = -1, i2m = -1, i3m = -1;
@@ -296,6 +327,8 @@ hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_d
     a.min_x = min_x, a.min_y = min_y;
     a.inv_w = (float)SFI_COLS / (max_x - min_x), a.inv_h = (float)SFI_ROWS / (max_y - min_y);
     a.r = (float)window, a.ratio = ratio, a.factor = ORBX_HISTO_LENGTH / 360.0f;
+    cap0 = (cap0 + 3) & ~3;  // 16-byte reads of the sort keys
+    a.cap0 = cap0;
     const size_t lds = orbx_search_init_lds_bytes(cap0);
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_init),
@@ -303,7 +336,7 @@ hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_d
         if (e != hipSuccess)
             return e;
     }
-    k_search_init<<<npairs, 64, lds, s>>>(d_kp, d_desc, d_counts, d_prev_in, d_prev_out, d_matches12, d_nmatches,
+    k_search_init<<<npairs, SFI_NT, lds, s>>>(d_kp, d_desc, d_counts, d_prev_in, d_prev_out, d_matches12, d_nmatches,
                                           d_pair_count, a);
     return hipGetLastError();
 }
