@@ -15,6 +15,8 @@
 // position order, and the packed key  distance<<16 | position  orders candidates exactly like the
 // strict '<' updates of that visit.  The two smallest keys of the wave are bestDist / bestDist2 /
 // bestIdx2.
+#include <algorithm>
+
 #include "orbx_internal.h"
 
 extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);  // wave-wide minimum (device library)
@@ -23,16 +25,18 @@ extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);  // wave-wide min
 #define SFI_ROWS 48  // FRAME_GRID_ROWS
 #define SFI_DSTRIDE 9  // dwords per staged descriptor (8 + 1 pad: lanes hit different LDS banks)
 #define SFI_NONE 0xffffu
+#define SFI_SLOW 0xffffffffu
 
 struct SfiArgs {
     int max_kp, npairs, cap0, check_ori, th_low, histo;
+    int keys_cap;  // candidate keys that fit the LDS behind the per-keypoint arrays
     float min_x, min_y, inv_w, inv_h, r, ratio, factor;
 };
 
 // bytes of dynamic LDS for `cap0` level-0 keypoints per frame
 size_t orbx_search_init_lds_bytes(int cap0)
 {
-    return (size_t)cap0 * (SFI_DSTRIDE * 4 + 4 * 7 + 2 * 6 + 4 + 32);
+    return (size_t)cap0 * (SFI_DSTRIDE * 4 + 4 * 7 + 2 * 6 + 4 + 32 + 8);
 }
 
 __device__ __forceinline__ int lanes_below64(unsigned long long m)
@@ -66,10 +70,18 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
     uint16_t *m21 = mdist + cap;                                 // vnMatches21 as position in frame 1's list
     uint16_t *idx1 = m21 + cap;                                  // index in frame 1's keypoint array
     uint16_t *m12 = idx1 + cap;                                  // vnMatches12 as position in frame 2's list
-    uint8_t *bin1 = reinterpret_cast<uint8_t *>(m12 + cap);      // rotation bin of an accepted match, 0xff: none
+    uint16_t *acc = m12 + cap;                                   // position in frame 2's list a keypoint was accepted for
+    uint8_t *bin1 = reinterpret_cast<uint8_t *>(acc + cap);      // rotation bin of an accepted match, 0xff: none
     // descriptors of frame 1's level-0 keypoints in list order: a query read from global memory would set the
     // pace of the walk (one memory latency per step)
     uint32_t *d1 = reinterpret_cast<uint32_t *>(bin1 + cap);     // cap * 8 dwords (cap is a multiple of 4)
+    // Candidate keys (distance << 16 | position) of every query, computed by all waves before the walk: the
+    // distances do not depend on the walk's state, only the vMatchedDistance filter does.  qoff[j] = first key
+    // of query j in `keys` (SFI_SLOW: its keys did not fit, the walk computes them itself), qcnt[j] their number.
+    uint32_t *qoff = d1 + (size_t)cap * 8;
+    uint32_t *qcnt = qoff + cap;
+    uint32_t *keys = qcnt + cap;  // a.keys_cap entries
+    __shared__ int s_alloc, s_npairs;
     __shared__ int hist[32];
     __shared__ int colstart[SFI_COLS + 1];  // first sorted position of each cell column
     __shared__ int s_wc[2][2][SFI_NT / 64];  // per chunk parity and frame: the waves' counts
@@ -84,6 +96,8 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
         out12[i] = -1;
     if (tid < 32)
         hist[tid] = 0;
+    if (tid == 0)
+        s_alloc = 0, s_npairs = 0;
 
     // ---- set-up by the whole workgroup ----
     // level-0 keypoints of frame 2 that lie in a grid cell (sort keys) and level-0 keypoints of frame 1, both
@@ -125,6 +139,7 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
             x1[pos1] = fx, y1[pos1] = fy, ang1[pos1] = fa;
             idx1[pos1] = (uint16_t)i;
             m12[pos1] = (uint16_t)SFI_NONE;
+            acc[pos1] = (uint16_t)SFI_NONE;
             bin1[pos1] = 0xff;
         }
         n20 += all2, n10 += all1;
@@ -177,6 +192,71 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
         colstart[c] = lo;
     }
     __syncthreads();
+    // cell window of GetFeaturesInArea as a range of sorted positions and a cell-row interval; an empty range
+    // leaves the keypoint unmatched
+    auto window = [&](float qx, float qy, int &c_lo, int &c_hi, int &cy0, int &cy1) {
+        const int cx0 = max(0, (int)floorf((qx - a.min_x - a.r) * a.inv_w));
+        const int cx1 = min(SFI_COLS - 1, (int)ceilf((qx - a.min_x + a.r) * a.inv_w));
+        cy0 = max(0, (int)floorf((qy - a.min_y - a.r) * a.inv_h));
+        cy1 = min(SFI_ROWS - 1, (int)ceilf((qy - a.min_y + a.r) * a.inv_h));
+        c_lo = c_hi = 0;
+        if (cx0 >= SFI_COLS || cx1 < 0 || cy0 >= SFI_ROWS || cy1 < 0)
+            return;
+        c_lo = __builtin_amdgcn_readfirstlane(colstart[cx0]);
+        c_hi = cx1 >= cx0 ? __builtin_amdgcn_readfirstlane(colstart[cx1 + 1]) : c_lo;
+    };
+    auto inside = [&](int c, float qx, float qy, int cy0, int cy1) -> bool {
+        const int py = cell2[c] & 0xff;
+        return py >= cy0 && py <= cy1 && fabsf(x2[c] - qx) < a.r && fabsf(y2[c] - qy) < a.r;
+    };
+    auto distance = [&](const uint32_t (&q)[8], int c) -> uint32_t {
+        const uint32_t *r = d2 + c * SFI_DSTRIDE;
+        uint32_t d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            d += __popc(q[k] ^ r[k]);
+        return d;
+    };
+    // ---- candidate keys of all queries, a wave per query ----
+    for (int j = wv; j < n10; j += SFI_NT / 64) {
+        const float qx = x1[j], qy = y1[j];
+        int c_lo = 0, c_hi = 0, cy0 = 0, cy1 = 0;
+        window(qx, qy, c_lo, c_hi, cy0, cy1);
+        // count first: the keys of a query are allocated in one piece
+        int cnt = 0;
+        for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+            const int c = c0 + lane;
+            cnt += __popcll(__ballot(c < c_hi && inside(c, qx, qy, cy0, cy1)));
+        }
+        uint32_t off = 0;
+        if (cnt > 0) {
+            int got = 0;
+            if (lane == 0)
+                got = atomicAdd(&s_alloc, cnt);
+            got = __builtin_amdgcn_readfirstlane(got);
+            off = got + cnt <= a.keys_cap ? (uint32_t)got : SFI_SLOW;
+        }
+        if (lane == 0)
+            qoff[j] = off, qcnt[j] = (uint32_t)cnt;
+        if (cnt == 0 || off == SFI_SLOW)
+            continue;
+        if (lane == 0)
+            atomicAdd(&s_npairs, cnt);
+        uint32_t q[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            q[k] = d1[j * 8 + k];
+        int at = (int)off;
+        for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+            const int c = c0 + lane;
+            const bool in = c < c_hi && inside(c, qx, qy, cy0, cy1);
+            const unsigned long long bm = __ballot(in);
+            if (in)
+                keys[at + lanes_below64(bm)] = (distance(q, c) << 16) | (uint32_t)c;
+            at += __popcll(bm);
+        }
+    }
+    __syncthreads();
     // The walk is sequential: the first wave does it alone.  From here on there is no workgroup barrier (the
     // other waves are gone); inside one wave LDS operations complete in program order, so a write by lane 0 is
     // seen by the reads of all lanes that follow it once the compiler keeps that order (wave_sync below).
@@ -186,79 +266,68 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
 
     // ---- the order-dependent pass (:446-516) ----
     int npairs = 0;
-    // the query of step j+1 (search centre, descriptor) is fetched while step j runs
-    float nqx = 0.f, nqy = 0.f;
-    uint32_t nq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto fetch_query = [&](int j) {
+    // what step j+1 reads first (its key range and its first 64 keys) is fetched while step j decides
+    uint32_t noff = 0, nkey = 0xffffffffu;
+    int ncnt = 0;
+    auto fetch_step = [&](int j) {
         if (j < n10) {
-            nqx = x1[j], nqy = y1[j];
-#pragma unroll
-            for (int k = 0; k < 8; k++)
-                nq[k] = d1[j * 8 + k];  // the same address in every lane: LDS broadcasts
+            noff = qoff[j], ncnt = (int)qcnt[j];
+            nkey = (noff != SFI_SLOW && lane < ncnt) ? keys[noff + lane] : 0xffffffffu;
         }
     };
-    fetch_query(0);
+    fetch_step(0);
     for (int j = 0; j < n10; j++) {
-        const float qx = nqx, qy = nqy;
-        uint32_t q[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            q[k] = nq[k];
-        fetch_query(j + 1);
-        // cell window of GetFeaturesInArea; an empty window leaves the keypoint unmatched
-        const int cx0 = max(0, (int)floorf((qx - a.min_x - a.r) * a.inv_w));
-        const int cx1 = min(SFI_COLS - 1, (int)ceilf((qx - a.min_x + a.r) * a.inv_w));
-        const int cy0 = max(0, (int)floorf((qy - a.min_y - a.r) * a.inv_h));
-        const int cy1 = min(SFI_ROWS - 1, (int)ceilf((qy - a.min_y + a.r) * a.inv_h));
-        if (cx0 >= SFI_COLS || cx1 < 0 || cy0 >= SFI_ROWS || cy1 < 0)
+        const uint32_t off = noff, key0 = nkey;
+        const int cnt = ncnt;
+        fetch_step(j + 1);
+        if (cnt == 0)
             continue;
-        const int c_lo = __builtin_amdgcn_readfirstlane(colstart[cx0]);
-        const int c_hi = cx1 >= cx0 ? __builtin_amdgcn_readfirstlane(colstart[cx1 + 1]) : c_lo;
         uint32_t b1 = 0xffffffffu, b2 = 0xffffffffu;
-        for (int c = c_lo + lane; c < c_hi; c += 64) {
-            const int py = cell2[c] & 0xff;
-            const bool in = py >= cy0 && py <= cy1 && fabsf(x2[c] - qx) < a.r && fabsf(y2[c] - qy) < a.r;
-            if (in) {
-                npairs++;
-                const uint32_t *r = d2 + c * SFI_DSTRIDE;
-                uint32_t d = 0;
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    d += __popc(q[k] ^ r[k]);
-                if (!((uint32_t)mdist[c] <= d)) {  // vMatchedDistance starts at INT_MAX
-                    const uint32_t key = (d << 16) | (uint32_t)c;
-                    const uint32_t hi = max(b1, key);
-                    b1 = min(b1, key);
-                    b2 = min(b2, hi);
-                }
+        auto offer = [&](uint32_t key) {
+            if (!((uint32_t)mdist[key & 0xffffu] <= (key >> 16))) {  // vMatchedDistance starts at INT_MAX
+                const uint32_t hi = max(b1, key);
+                b1 = min(b1, key);
+                b2 = min(b2, hi);
             }
+        };
+        if (off != SFI_SLOW) {
+            if (lane < cnt)
+                offer(key0);
+            for (int e = 64 + lane; e < cnt; e += 64)
+                offer(keys[off + e]);
+        } else {
+            // the keys of this query did not fit: computed here
+            const float qx = x1[j], qy = y1[j];
+            uint32_t q[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                q[k] = d1[j * 8 + k];
+            int c_lo = 0, c_hi = 0, cy0 = 0, cy1 = 0;
+            window(qx, qy, c_lo, c_hi, cy0, cy1);
+            for (int c = c_lo + lane; c < c_hi; c += 64)
+                if (inside(c, qx, qy, cy0, cy1)) {
+                    npairs++;
+                    offer((distance(q, c) << 16) | (uint32_t)c);
+                }
         }
         const uint32_t w1 = __ockl_wfred_min_u32(b1);
         if (w1 == 0xffffffffu)
             continue;
         // the runner-up is the winner lane's second key or another lane's first (keys are distinct)
+        const int old21 = m21[w1 & 0xffffu];  // in flight while the runner-up is found
         const uint32_t w2 = __ockl_wfred_min_u32(b1 == w1 ? b2 : b1);
         const int best = (int)(w1 >> 16);
         const float best2 = w2 == 0xffffffffu ? 2147483648.0f : (float)(int)(w2 >> 16);  // INT_MAX as float
         if (best <= a.th_low && (float)best < best2 * a.ratio) {
             const int c = (int)(w1 & 0xffffu);
             if (lane == 0) {
-                const int old = m21[c];
+                const int old = old21;
                 if (old != (int)SFI_NONE)
                     m12[old] = (uint16_t)SFI_NONE;
                 m12[j] = (uint16_t)c;
                 m21[c] = (uint16_t)j;
                 mdist[c] = (uint16_t)best;
-                if (a.check_ori) {
-                    float rot = ang1[j] - ang2[c];
-                    if (rot < 0.0f)
-                        rot += 360.0f;
-                    int bin = (int)roundf(rot * a.factor);
-                    if (bin == a.histo)
-                        bin = 0;
-                    bin1[j] = (uint8_t)bin;
-                    hist[bin & 31]++;
-                }
+                acc[j] = (uint16_t)c;
             }
             wave_sync();  // lane 0's updates are read by every lane from here on
         }
@@ -266,6 +335,25 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
     wave_sync();
 
     // ---- rotation consistency (:502-541, ComputeThreeMaxima :1698-1739) ----
+    // The histogram holds every acceptance of the walk, also those whose feature a later keypoint took over
+    // (the reference pushes at acceptance and never removes, :502-513); the bins are worked out here, for all
+    // keypoints at once, instead of inside the walk.
+    if (a.check_ori) {
+        for (int j = lane; j < n10; j += 64) {
+            const int c = acc[j];
+            if (c != (int)SFI_NONE) {
+                float rot = ang1[j] - ang2[c];
+                if (rot < 0.0f)
+                    rot += 360.0f;
+                int bin = (int)roundf(rot * a.factor);
+                if (bin == a.histo)
+                    bin = 0;
+                bin1[j] = (uint8_t)bin;
+                atomicAdd(&hist[bin & 31], 1);
+            }
+        }
+        wave_sync();
+    }
     int i1m = -1, i2m = -1, i3m = -1;
     if (a.check_ori) {
         int max1 = 0, max2 = 0, max3 = 0;
@@ -311,7 +399,7 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
         npairs += __shfl_xor(npairs, s, 64);
     }
     if (lane == 0)
-        nmatches[p] = nm, pair_count[p] = npairs;
+        nmatches[p] = nm, pair_count[p] = npairs + s_npairs;
 }
 
 hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_desc, const int *d_counts, int max_kp,
@@ -329,7 +417,11 @@ hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_d
     a.r = (float)window, a.ratio = ratio, a.factor = ORBX_HISTO_LENGTH / 360.0f;
     cap0 = (cap0 + 3) & ~3;  // 16-byte reads of the sort keys
     a.cap0 = cap0;
-    const size_t lds = orbx_search_init_lds_bytes(cap0);
+    // the LDS left of 150 KB holds candidate keys (at most 128 per query): a workgroup then has a compute unit
+    // to itself, which is what a launch of a few hundred pairs gets anyway
+    const size_t base = orbx_search_init_lds_bytes(cap0), budget = 150 * 1024;
+    a.keys_cap = (int)std::min<size_t>(base < budget ? (budget - base) / 4 : 0, (size_t)cap0 * 128);
+    const size_t lds = base + (size_t)a.keys_cap * 4;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_search_init),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
