@@ -418,8 +418,9 @@ hipError_t orbx_launch_search_init(const orbx_keypoint *d_kp, const uint8_t *d_d
     cap0 = (cap0 + 3) & ~3;  // 16-byte reads of the sort keys
     a.cap0 = cap0;
     // the LDS left of 150 KB holds candidate keys (at most 128 per query): a workgroup then has a compute unit
-    // to itself, which is what a launch of a few hundred pairs gets anyway
-    const size_t base = orbx_search_init_lds_bytes(cap0), budget = 150 * 1024;
+    // to itself, which is what a launch of up to 256 pairs (one per compute unit) gets anyway; larger launches
+    // keep two workgroups on a compute unit and fewer keys
+    const size_t base = orbx_search_init_lds_bytes(cap0), budget = (npairs <= 256 ? 150 : 76) * 1024;
     a.keys_cap = (int)std::min<size_t>(base < budget ? (budget - base) / 4 : 0, (size_t)cap0 * 128);
     const size_t lds = base + (size_t)a.keys_cap * 4;
     if (lds > 48 * 1024) {
