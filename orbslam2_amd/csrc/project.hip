@@ -13,6 +13,8 @@
 //      of the reference does,
 //   4. k_proj_finish builds the rotation histogram of the accepted matches (:1528-1540) and clears
 //      those outside its three fullest bins (:1542-1560).
+#include <type_traits>
+
 #include "orbx_internal.h"
 
 extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);  // wave-wide minimum (device library)
@@ -106,68 +108,75 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
         for (int g = 0; g < nsrc; g++) {
             const int s = s0 + g;
             const int cnt = s_cnt[g];
-            int idx[PROJ_SLOTS];
-            uint32_t ent[PROJ_SLOTS];
+            // one decision, on SLOTS candidates per lane: nearly every window holds at most 32 candidates (one
+            // slot, staged in LDS); the four-slot form serves the crowded ones from global memory
+            auto decide = [&](auto slots_tag) -> int {
+                constexpr int SLOTS = decltype(slots_tag)::value;
+                int idx[SLOTS];
+                uint32_t ent[SLOTS];
 #pragma unroll
-            for (int k = 0; k < PROJ_SLOTS; k++)
-                idx[k] = -1, ent[k] = PROJ_SKIP;
-            if (cnt <= PROJ_STAGE) {
-                if (lane < cnt) {
-                    const uint2 ce = s_ce[g][lane];
-                    idx[0] = (int)ce.x, ent[0] = ce.y;
-                }
-            } else {  // rare: a crowded window
+                for (int k = 0; k < SLOTS; k++)
+                    idx[k] = -1, ent[k] = PROJ_SKIP;
+                if constexpr (SLOTS == 1) {
+                    if (lane < cnt) {
+                        const uint2 ce = s_ce[g][lane];
+                        idx[0] = (int)ce.x, ent[0] = ce.y;
+                    }
+                } else {
 #pragma unroll
-                for (int k = 0; k < PROJ_SLOTS; k++) {
-                    const int j = lane + 64 * k;
-                    if (j < min(cnt, a.cap)) {
-                        idx[k] = list[(size_t)s * a.cap + j];
-                        ent[k] = entry[(size_t)s * a.cap + j];
+                    for (int k = 0; k < SLOTS; k++) {
+                        const int j = lane + 64 * k;
+                        if (j < min(cnt, a.cap)) {
+                            idx[k] = list[(size_t)s * a.cap + j];
+                            ent[k] = entry[(size_t)s * a.cap + j];
+                        }
                     }
                 }
-            }
-            int m = -1;
-            if (cnt > a.cap)
-                overflow = 1;
-            if (cnt > 0) {
                 uint32_t mine = PROJ_SKIP;
 #pragma unroll
-                for (int k = 0; k < PROJ_SLOTS; k++) {
+                for (int k = 0; k < SLOTS; k++) {
                     if (idx[k] >= 0 && ((taken[idx[k] >> 5] >> (idx[k] & 31)) & 1u))
                         ent[k] = PROJ_SKIP;
                     mine = min(mine, ent[k]);
                 }
                 const uint32_t best = __ockl_wfred_min_u32(mine);
-                if (best != PROJ_SKIP) {
-                    const int best_d = (int)(best >> 20);
-                    bool ok = best_d <= a.th_dist;
-                    if (ok && a.use_second) {
-                        uint32_t rest = PROJ_SKIP;
+                if (best == PROJ_SKIP)
+                    return -1;
+                const int best_d = (int)(best >> 20);
+                if (best_d > a.th_dist)
+                    return -1;
+                if (a.use_second) {
+                    uint32_t rest = PROJ_SKIP;
 #pragma unroll
-                        for (int k = 0; k < PROJ_SLOTS; k++)
-                            rest = min(rest, ent[k] == best ? PROJ_SKIP : ent[k]);
-                        const uint32_t second = __ockl_wfred_min_u32(rest);
-                        // no second candidate: bestLevel2 stays -1 and differs from any level (:118-126)
-                        if (second != PROJ_SKIP && (best & 15u) == (second & 15u) &&
-                            (float)best_d > __fmul_rn(a.nnratio, (float)(int)(second >> 20)))
-                            ok = false;
-                    }
-                    if (ok) {
-                        int cand = -1;
-#pragma unroll
-                        for (int k = 0; k < PROJ_SLOTS; k++)
-                            if (ent[k] == best)
-                                cand = idx[k];
-                        m = __ockl_wfred_max_i32(cand);
-                        nmatches++;
-                        if (lane == 0) {
-                            const uint32_t bit = 1u << (m & 31);
-                            taken[m >> 5] = s_blk[g] ? (taken[m >> 5] | bit) : (taken[m >> 5] & ~bit);
-                            feature_match[m] = s;
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                    for (int k = 0; k < SLOTS; k++)
+                        rest = min(rest, ent[k] == best ? PROJ_SKIP : ent[k]);
+                    const uint32_t second = __ockl_wfred_min_u32(rest);
+                    // no second candidate: bestLevel2 stays -1 and differs from any level (:118-126)
+                    if (second != PROJ_SKIP && (best & 15u) == (second & 15u) &&
+                        (float)best_d > __fmul_rn(a.nnratio, (float)(int)(second >> 20)))
+                        return -1;
                 }
+                int cand = -1;
+#pragma unroll
+                for (int k = 0; k < SLOTS; k++)
+                    if (ent[k] == best)
+                        cand = idx[k];
+                return __ockl_wfred_max_i32(cand);
+            };
+            int m = -1;
+            if (cnt > a.cap)
+                overflow = 1;
+            if (cnt > 0)
+                m = cnt <= PROJ_STAGE ? decide(std::integral_constant<int, 1>{})
+                                      : decide(std::integral_constant<int, PROJ_SLOTS>{});
+            if (m >= 0) {
+                nmatches++;
+                if (lane == 0) {
+                    const uint32_t bit = 1u << (m & 31);
+                    taken[m >> 5] = s_blk[g] ? (taken[m >> 5] | bit) : (taken[m >> 5] & ~bit);
+                    feature_match[m] = s;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
             if (lane == 0)
                 match[s] = m;
