@@ -1103,6 +1103,10 @@ struct orbx_matcher {
     // one allocation carved into the arrays of a SearchByBoW call
     uint8_t *d_ws;
     size_t ws_cap;
+    // page-locked mirror of the input and result parts of d_ws: the host-array entry points gather their
+    // arguments there and move them with one copy each way instead of one per array
+    uint8_t *h_ws;
+    size_t h_ws_cap;
     bool force_valu;  // brute-force top-2 on the vector ALUs even for large query sets (ORBX_TOP2=valu)
 };
 
@@ -1151,6 +1155,8 @@ extern "C" void orbx_matcher_destroy(orbx_matcher *m)
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
+    if (m->h_ws)
+        (void)hipHostFree(m->h_ws);
     if (m->own_stream)
         (void)hipStreamDestroy(m->own_stream);
     delete m;
@@ -1176,6 +1182,21 @@ template <typename T> static int grow(T **p, size_t *cap, size_t need, hipStream
     const size_t n = need + need / 4;
     HIP_TRY(hipMalloc((void **)p, n * sizeof(T)));
     *cap = n;
+    return ORBX_OK;
+}
+
+static int grow_pinned(orbx_matcher *m, size_t need)
+{
+    if (need <= m->h_ws_cap)
+        return ORBX_OK;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (m->h_ws)
+        HIP_TRY(hipHostFree(m->h_ws));
+    m->h_ws = nullptr;
+    m->h_ws_cap = 0;
+    const size_t n = need + need / 4;
+    HIP_TRY(hipHostMalloc((void **)&m->h_ws, n, hipHostMallocDefault));
+    m->h_ws_cap = n;
     return ORBX_OK;
 }
 
@@ -1700,35 +1721,43 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *k
         off += (std::max<size_t>(bytes, 4) + 255) / 256 * 256;
         return at;
     };
+    // inputs first, results next, scratch last: the first two parts are mirrored in page-locked memory
     const size_t o_kp = carve((size_t)n * sizeof(orbx_keypoint)), o_desc = carve((size_t)n * 32);
-    const size_t o_ur = carve((size_t)n * 4), o_tk = carve((size_t)n), o_cs = carve((size_t)(64 * 48 + 1) * 4);
-    const size_t o_ci = carve((size_t)n * 4), o_fm = carve((size_t)n * 4);
+    const size_t o_ur = carve((size_t)n * 4), o_tk = carve((size_t)n);
     const size_t o_va = carve((size_t)ns), o_x = carve((size_t)ns * 4), o_y = carve((size_t)ns * 4);
     const size_t o_r = carve((size_t)ns * 4), o_lo = carve((size_t)ns * 4), o_hi = carve((size_t)ns * 4);
     const size_t o_xr = carve((size_t)ns * 4), o_sd = carve((size_t)ns * 32), o_bl = carve((size_t)ns);
-    const size_t o_an = carve((size_t)ns * 4), o_list = carve((size_t)ns * cap * 4), o_cnt = carve((size_t)ns * 4);
-    const size_t o_ent = carve((size_t)ns * cap * 4), o_m = carve((size_t)ns * 4), o_res = carve(8);
+    const size_t o_an = carve((size_t)ns * 4);
+    const size_t in_bytes = off;
+    const size_t o_m = carve((size_t)ns * 4), o_fm = carve((size_t)n * 4), o_res = carve(8);
+    const size_t out_bytes = off - in_bytes;
+    const size_t o_cs = carve((size_t)(64 * 48 + 1) * 4), o_ci = carve((size_t)n * 4);
+    const size_t o_list = carve((size_t)ns * cap * 4), o_cnt = carve((size_t)ns * 4), o_ent = carve((size_t)ns * cap * 4);
     int rc = grow(&m->d_ws, &m->ws_cap, off, m->stream);
+    if (rc == ORBX_OK)
+        rc = grow_pinned(m, std::max(in_bytes, out_bytes));
     if (rc != ORBX_OK)
         return rc;
     uint8_t *w = m->d_ws;
-    auto up = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
-        return (bytes && src) ? hipMemcpyAsync(w + at, src, bytes, hipMemcpyHostToDevice, m->stream) : hipSuccess;
+    auto put = [&](size_t at, const void *src, size_t bytes) {
+        if (bytes && src)
+            memcpy(m->h_ws + at, src, bytes);
     };
-    HIP_TRY(up(o_kp, keypoints, (size_t)n * sizeof(orbx_keypoint)));
-    HIP_TRY(up(o_desc, descriptors, (size_t)n * 32));
-    HIP_TRY(up(o_ur, uright, (size_t)n * 4));
-    HIP_TRY(up(o_tk, taken, (size_t)n));
-    HIP_TRY(up(o_va, valid, (size_t)ns));
-    HIP_TRY(up(o_x, x, (size_t)ns * 4));
-    HIP_TRY(up(o_y, y, (size_t)ns * 4));
-    HIP_TRY(up(o_r, r, (size_t)ns * 4));
-    HIP_TRY(up(o_lo, min_level, (size_t)ns * 4));
-    HIP_TRY(up(o_hi, max_level, (size_t)ns * 4));
-    HIP_TRY(up(o_xr, xr, (size_t)ns * 4));
-    HIP_TRY(up(o_sd, src_desc, (size_t)ns * 32));
-    HIP_TRY(up(o_bl, blocks, (size_t)ns));
-    HIP_TRY(up(o_an, src_angle, (size_t)ns * 4));
+    put(o_kp, keypoints, (size_t)n * sizeof(orbx_keypoint));
+    put(o_desc, descriptors, (size_t)n * 32);
+    put(o_ur, uright, (size_t)n * 4);
+    put(o_tk, taken, (size_t)n);
+    put(o_va, valid, (size_t)ns);
+    put(o_x, x, (size_t)ns * 4);
+    put(o_y, y, (size_t)ns * 4);
+    put(o_r, r, (size_t)ns * 4);
+    put(o_lo, min_level, (size_t)ns * 4);
+    put(o_hi, max_level, (size_t)ns * 4);
+    put(o_xr, xr, (size_t)ns * 4);
+    put(o_sd, src_desc, (size_t)ns * 32);
+    put(o_bl, blocks, (size_t)ns);
+    put(o_an, src_angle, (size_t)ns * 4);
+    HIP_TRY(hipMemcpyAsync(w, m->h_ws, in_bytes, hipMemcpyHostToDevice, m->stream));
     const orbx_keypoint *d_kp = (const orbx_keypoint *)(w + o_kp);
     rc = orbx_frame_grid_build_device(m, d_kp, n, min_x, max_x, min_y, max_y, (int32_t *)(w + o_cs), (int32_t *)(w + o_ci));
     if (rc != ORBX_OK)
@@ -1745,15 +1774,18 @@ extern "C" int orbx_search_by_projection(orbx_matcher *m, const orbx_keypoint *k
         blocks ? w + o_bl : nullptr, src_angle ? (const float *)(w + o_an) : nullptr, ns, (const int32_t *)(w + o_list),
         (const int32_t *)(w + o_cnt), cap, (uint32_t *)(w + o_ent), use_second, nnratio, th_dist, check_orientation,
         (int32_t *)(w + o_m), (int32_t *)(w + o_fm), (int32_t *)(w + o_res), m->stream));
-    int32_t res[2] = {0, 0};
-    if (ns > 0)
-        HIP_TRY(hipMemcpyAsync(match, w + o_m, (size_t)ns * 4, hipMemcpyDeviceToHost, m->stream));
-    if (n > 0)
-        HIP_TRY(hipMemcpyAsync(feature_match, w + o_fm, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(res, w + o_res, 8, hipMemcpyDeviceToHost, m->stream));
+    // the results in one copy (the upload out of the mirror has long finished: same stream)
+    HIP_TRY(hipMemcpyAsync(m->h_ws, w + o_m, out_bytes, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    const uint8_t *h = m->h_ws;
+    int32_t res[2];
+    memcpy(res, h + (o_res - o_m), 8);
     if (res[1])
         return ORBX_E_CAPACITY;
+    if (ns > 0)
+        memcpy(match, h, (size_t)ns * 4);
+    if (n > 0)
+        memcpy(feature_match, h + (o_fm - o_m), (size_t)n * 4);
     *nmatches = res[0];
     return ORBX_OK;
 }
@@ -1859,30 +1891,38 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const f
     const size_t o_s1 = carve((size_t)(E1 + 1) * 4), o_t1 = carve((size_t)I1 * 4);
     const size_t o_d2 = carve((size_t)n2 * 32), o_a2 = carve((size_t)n2 * 4), o_v2 = carve((size_t)n2);
     const size_t o_i2 = carve((size_t)m2 * 4), o_s2 = carve((size_t)(m2 + 1) * 4), o_t2 = carve((size_t)I2 * 4);
+    const size_t in_bytes = off;  // everything above comes from the caller
     const size_t o_m12 = carve((size_t)F1 * 4), o_m21 = carve((size_t)nb * std::max(n2, 1) * 4);
-    const size_t o_nm = carve((size_t)nb * 4), o_bin = carve((size_t)F1), o_h = carve((size_t)nb * 32 * 4);
-    const size_t o_st = carve(4);
+    const size_t o_nm = carve((size_t)nb * 4), o_st = carve(4);
+    const size_t out_bytes = off - in_bytes;  // and these go back
+    const size_t o_bin = carve((size_t)F1), o_h = carve((size_t)nb * 32 * 4);
     int rc = grow(&m->d_ws, &m->ws_cap, off, m->stream);
+    if (rc == ORBX_OK)
+        rc = grow_pinned(m, std::max(in_bytes, out_bytes));
     if (rc != ORBX_OK)
         return rc;
     uint8_t *w = m->d_ws;
-    auto up = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpyAsync(w + at, src, bytes, hipMemcpyHostToDevice, m->stream) : hipSuccess;
+    auto put = [&](size_t at, const void *src, size_t bytes) {
+        if (bytes && src)
+            memcpy(m->h_ws + at, src, bytes);
     };
-    HIP_TRY(up(o_d1, desc1, (size_t)F1 * 32));
-    HIP_TRY(up(o_a1, angle1, (size_t)F1 * 4));
-    if (valid1) HIP_TRY(up(o_v1, valid1, (size_t)F1));
-    HIP_TRY(up(o_fs, feat_start, (size_t)(nb + 1) * 4));
-    HIP_TRY(up(o_nk, node_kf.data(), (size_t)E1 * 4));
-    HIP_TRY(up(o_i1, node_ids1, (size_t)E1 * 4));
-    if (E1 > 0) HIP_TRY(up(o_s1, node_start1, (size_t)(E1 + 1) * 4));
-    HIP_TRY(up(o_t1, node_items1, (size_t)I1 * 4));
-    HIP_TRY(up(o_d2, desc2, (size_t)n2 * 32));
-    HIP_TRY(up(o_a2, angle2, (size_t)n2 * 4));
-    if (valid2) HIP_TRY(up(o_v2, valid2, (size_t)n2));
-    HIP_TRY(up(o_i2, node_ids2, (size_t)m2 * 4));
-    if (m2 > 0) HIP_TRY(up(o_s2, node_start2, (size_t)(m2 + 1) * 4));
-    HIP_TRY(up(o_t2, node_items2, (size_t)I2 * 4));
+    put(o_d1, desc1, (size_t)F1 * 32);
+    put(o_a1, angle1, (size_t)F1 * 4);
+    put(o_v1, valid1, (size_t)F1);
+    put(o_fs, feat_start, (size_t)(nb + 1) * 4);
+    put(o_nk, node_kf.data(), (size_t)E1 * 4);
+    put(o_i1, node_ids1, (size_t)E1 * 4);
+    if (E1 > 0)
+        put(o_s1, node_start1, (size_t)(E1 + 1) * 4);
+    put(o_t1, node_items1, (size_t)I1 * 4);
+    put(o_d2, desc2, (size_t)n2 * 32);
+    put(o_a2, angle2, (size_t)n2 * 4);
+    put(o_v2, valid2, (size_t)n2);
+    put(o_i2, node_ids2, (size_t)m2 * 4);
+    if (m2 > 0)
+        put(o_s2, node_start2, (size_t)(m2 + 1) * 4);
+    put(o_t2, node_items2, (size_t)I2 * 4);
+    HIP_TRY(hipMemcpyAsync(w, m->h_ws, in_bytes, hipMemcpyHostToDevice, m->stream));
     HIP_TRY(orbx_launch_bow(w + o_d1, (const float *)(w + o_a1), valid1 ? w + o_v1 : nullptr, (const int *)(w + o_fs), nb,
                             F1, (const int *)(w + o_nk), (const int *)(w + o_i1), (const int *)(w + o_s1),
                             (const int *)(w + o_t1), E1, w + o_d2, (const float *)(w + o_a2),
@@ -1890,14 +1930,16 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const f
                             (const int *)(w + o_t2), m2, strict_lt, nnratio, check_orientation, (int *)(w + o_m12),
                             (int *)(w + o_m21), (int *)(w + o_nm), (int8_t *)(w + o_bin), (int *)(w + o_h),
                             (int *)(w + o_st), m->stream));
-    int status = 0;
-    if (F1 > 0)
-        HIP_TRY(hipMemcpyAsync(match12, w + o_m12, (size_t)F1 * 4, hipMemcpyDeviceToHost, m->stream));
-    if (n2 > 0)
-        HIP_TRY(hipMemcpyAsync(match21, w + o_m21, (size_t)nb * n2 * 4, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(nmatches, w + o_nm, (size_t)nb * 4, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipMemcpyAsync(&status, w + o_st, 4, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(m->h_ws, w + o_m12, out_bytes, hipMemcpyDeviceToHost, m->stream));
     HIP_TRY(hipStreamSynchronize(m->stream));
+    const uint8_t *h = m->h_ws;
+    int status = 0;
+    memcpy(&status, h + (o_st - o_m12), 4);
+    if (F1 > 0)
+        memcpy(match12, h, (size_t)F1 * 4);
+    if (n2 > 0)
+        memcpy(match21, h + (o_m21 - o_m12), (size_t)nb * n2 * 4);
+    memcpy(nmatches, h + (o_nm - o_m12), (size_t)nb * 4);
     return status ? ORBX_E_CAPACITY : ORBX_OK;
 }
 
