@@ -1659,23 +1659,31 @@ extern "C" int orbx_features_in_area(orbx_matcher *m, const orbx_keypoint *keypo
         off += (std::max<size_t>(bytes, 4) + 255) / 256 * 256;
         return at;
     };
-    const size_t o_kp = carve((size_t)n * sizeof(orbx_keypoint)), o_cs = carve((size_t)(64 * 48 + 1) * 4);
-    const size_t o_ci = carve((size_t)n * 4), o_x = carve((size_t)nq * 4), o_y = carve((size_t)nq * 4);
+    // inputs first, results next: both parts are mirrored in page-locked memory and move in one copy each
+    const size_t o_kp = carve((size_t)n * sizeof(orbx_keypoint));
+    const size_t o_x = carve((size_t)nq * 4), o_y = carve((size_t)nq * 4);
     const size_t o_r = carve((size_t)nq * 4), o_lo = carve((size_t)nq * 4), o_hi = carve((size_t)nq * 4);
-    const size_t o_out = carve((size_t)nq * cap * 4), o_n = carve((size_t)nq * 4);
+    const size_t in_bytes = off;
+    const size_t o_n = carve((size_t)nq * 4), o_cs = carve((size_t)(64 * 48 + 1) * 4), o_ci = carve((size_t)n * 4);
+    const size_t o_out = carve((size_t)nq * cap * 4);
+    const size_t out_bytes = off - in_bytes;
     int rc = grow(&m->d_ws, &m->ws_cap, off, m->stream);
+    if (rc == ORBX_OK)
+        rc = grow_pinned(m, std::max(in_bytes, out_bytes));
     if (rc != ORBX_OK)
         return rc;
     uint8_t *w = m->d_ws;
-    auto up = [&](size_t at, const void *src, size_t bytes) -> hipError_t {
-        return bytes ? hipMemcpyAsync(w + at, src, bytes, hipMemcpyHostToDevice, m->stream) : hipSuccess;
+    auto put = [&](size_t at, const void *src, size_t bytes) {
+        if (bytes && src)
+            memcpy(m->h_ws + at, src, bytes);
     };
-    HIP_TRY(up(o_kp, keypoints, (size_t)n * sizeof(orbx_keypoint)));
-    HIP_TRY(up(o_x, x, (size_t)nq * 4));
-    HIP_TRY(up(o_y, y, (size_t)nq * 4));
-    HIP_TRY(up(o_r, r, (size_t)nq * 4));
-    HIP_TRY(up(o_lo, min_level, (size_t)nq * 4));
-    HIP_TRY(up(o_hi, max_level, (size_t)nq * 4));
+    put(o_kp, keypoints, (size_t)n * sizeof(orbx_keypoint));
+    put(o_x, x, (size_t)nq * 4);
+    put(o_y, y, (size_t)nq * 4);
+    put(o_r, r, (size_t)nq * 4);
+    put(o_lo, min_level, (size_t)nq * 4);
+    put(o_hi, max_level, (size_t)nq * 4);
+    HIP_TRY(hipMemcpyAsync(w, m->h_ws, in_bytes, hipMemcpyHostToDevice, m->stream));
     rc = orbx_frame_grid_build_device(m, (const orbx_keypoint *)(w + o_kp), n, min_x, max_x, min_y, max_y,
                                       (int32_t *)(w + o_cs), (int32_t *)(w + o_ci));
     if (rc != ORBX_OK)
@@ -1686,16 +1694,20 @@ extern "C" int orbx_features_in_area(orbx_matcher *m, const orbx_keypoint *keypo
                                       (const int32_t *)(w + o_hi), nq, cap, (int32_t *)(w + o_out), (int32_t *)(w + o_n));
     if (rc != ORBX_OK)
         return rc;
+    // counts and grid always, the index lists only when there are any (they are the bulk)
+    const size_t back = (nq > 0 && cap > 0) ? out_bytes : o_out - o_n;
+    HIP_TRY(hipMemcpyAsync(m->h_ws, w + o_n, back, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    const uint8_t *h = m->h_ws;
     if (nq > 0) {
         if (cap > 0)
-            HIP_TRY(hipMemcpyAsync(out_idx, w + o_out, (size_t)nq * cap * 4, hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipMemcpyAsync(out_n, w + o_n, (size_t)nq * 4, hipMemcpyDeviceToHost, m->stream));
+            memcpy(out_idx, h + (o_out - o_n), (size_t)nq * cap * 4);
+        memcpy(out_n, h, (size_t)nq * 4);
     }
     if (cell_start)
-        HIP_TRY(hipMemcpyAsync(cell_start, w + o_cs, (size_t)(64 * 48 + 1) * 4, hipMemcpyDeviceToHost, m->stream));
+        memcpy(cell_start, h + (o_cs - o_n), (size_t)(64 * 48 + 1) * 4);
     if (cell_items && n > 0)
-        HIP_TRY(hipMemcpyAsync(cell_items, w + o_ci, (size_t)n * 4, hipMemcpyDeviceToHost, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+        memcpy(cell_items, h + (o_ci - o_n), (size_t)n * 4);
     return ORBX_OK;
 }
 
