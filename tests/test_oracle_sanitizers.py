@@ -1,5 +1,6 @@
 """The CPU oracle (test infrastructure, plain C) under AddressSanitizer and UndefinedBehaviorSanitizer: a native
-driver runs the extraction at five image sizes with both blur kernels and a top-2 match; any report fails."""
+driver runs the extraction at five image sizes with both blur kernels, a top-2 match and the frame-level matchers
+(initialisation search, grid queries, undistortion, distinctive descriptor, the three projection forms); any report fails."""
 import os
 import shutil
 import subprocess
