@@ -13,7 +13,6 @@
 
 #include "orbx_internal.h"
 
-extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);
 
 #define BOW_NODE_CAP 4096  // features of side 2 in one vocabulary node that a wave can flag in LDS
 
@@ -84,10 +83,10 @@ __global__ __launch_bounds__(64) void k_bow_match(const uint32_t *__restrict__ d
                 b2 = min(b2, h);
             }
         }
-        const uint32_t w1 = __ockl_wfred_min_u32(b1);
+        const uint32_t w1 = orbx_wave_min_u32(b1);
         if (w1 == 0xffffffffu)
             continue;
-        const uint32_t w2 = __ockl_wfred_min_u32(b1 == w1 ? b2 : b1);
+        const uint32_t w2 = orbx_wave_min_u32(b1 == w1 ? b2 : b1);
         const int best = (int)(w1 >> 16), best2 = w2 == 0xffffffffu ? 256 : (int)(w2 >> 16);
         if ((a.strict_lt ? best < a.th_low : best <= a.th_low) && (float)best < a.ratio * (float)best2) {
             const int c = (int)(w1 & 0xffffu);

@@ -127,7 +127,6 @@ struct FastArgs {
     uint32_t wc_magic[ORBX_MAX_LEVELS], hc_magic[ORBX_MAX_LEVELS];  // ceil(2^20 / cell size)
 };
 
-extern "C" __device__ int __ockl_wfscan_add_i32(int, bool);  // wave-wide prefix sum (device library)
 
 __device__ __forceinline__ int lanes_below(unsigned long long m)
 {
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         }
         // queue slots: a wave-wide prefix sum of the per-lane counts, one LDS atomic per wave
         const int cnt = __popc(acc);
-        const int incl = __ockl_wfscan_add_i32(cnt, true);
+        const int incl = orbx_wave_scan_add_i32(cnt);
         const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total) {
             int base = 0;

@@ -203,7 +203,6 @@ __device__ __forceinline__ uint32_t distinctive_row_median(const uint32_t *__res
     return (uint32_t)lo;
 }
 
-extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);
 
 __global__ __launch_bounds__(64) void k_distinctive(const uint32_t *__restrict__ desc, const int *__restrict__ seg_start,
                                                     int npoints, int32_t *__restrict__ best_idx,
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint32_t *__restrict__
                 best = min(best, (m << 20) | (uint32_t)i);
         }
     }
-    best = __ockl_wfred_min_u32(best);
+    best = orbx_wave_min_u32(best);
     const int bi = (int)(best & 0xfffffu);
     if (lane == 0)
         best_idx[p] = bi;

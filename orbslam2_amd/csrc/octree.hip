@@ -58,7 +58,6 @@ struct OctLds {
 
 size_t orbx_octree_lds_bytes(int node_cap) { return ((size_t)OCT_ARRAYS * node_cap + OCT_TAIL_INTS) * sizeof(int); }
 
-extern "C" __device__ int __ockl_wfscan_add_i32(int, bool);  // wave-wide prefix sum (device library, DPP)
 
 // Exclusive prefix of one value per thread over the workgroup; *total = its sum.  wsum holds two sets of
 // NT/64 wave sums used in turn (`phase` counts the calls, uniformly): a set is rewritten only after every
@@ -66,7 +65,7 @@ extern "C" __device__ int __ockl_wfscan_add_i32(int, bool);  // wave-wide prefix
 template <int NT>
 __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &phase, int *total)
 {
-    const int inc = __ockl_wfscan_add_i32(v, true);
+    const int inc = orbx_wave_scan_add_i32(v);
     const int wv = threadIdx.x >> 6;
     int *ws = wsum + (phase & 1) * (NT / 64);
     phase++;

@@ -110,6 +110,41 @@ static inline dim3 orbx_frame_grid(int units_per_frame, int batch)
 #if defined(__HIPCC__)
 #define ORBX_BLOCK_FRAME ((int)(blockIdx.z * gridDim.x + blockIdx.x))  // may be >= batch in the last group
 #define ORBX_BLOCK_UNIT ((int)blockIdx.y)
+
+// Wave-wide (64 lanes) prefix and reduction steps on the data-parallel-primitive paths of the vector ALU:
+// four shifts inside the rows of 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into
+// rows 2 and 3.  Six dependent instructions; the device library's __ockl_wfred_* / __ockl_wfscan_* compile to
+// six LDS-crossbar permutes here, each a round trip of about a hundred clocks, which sets the pace of every
+// kernel that walks a list in order.
+#define ORBX_DPP_STEP(OP, T, v, ident, ctrl, rows) \
+    v = OP(v, (T)__builtin_amdgcn_update_dpp((int)(ident), (int)(v), ctrl, rows, 0xf, false))
+#define ORBX_DPP_SCAN(OP, T, v, ident)            \
+    ORBX_DPP_STEP(OP, T, v, ident, 0x111, 0xf);  /* row_shr:1 */  \
+    ORBX_DPP_STEP(OP, T, v, ident, 0x112, 0xf);  /* row_shr:2 */  \
+    ORBX_DPP_STEP(OP, T, v, ident, 0x114, 0xf);  /* row_shr:4 */  \
+    ORBX_DPP_STEP(OP, T, v, ident, 0x118, 0xf);  /* row_shr:8 */  \
+    ORBX_DPP_STEP(OP, T, v, ident, 0x142, 0xa);  /* row_bcast:15 */ \
+    ORBX_DPP_STEP(OP, T, v, ident, 0x143, 0xc)   /* row_bcast:31 */
+__device__ __forceinline__ uint32_t orbx_op_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ int orbx_op_max_i32(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int orbx_op_add_i32(int a, int b) { return a + b; }
+// minimum / maximum over the wave, the same value in every lane
+__device__ __forceinline__ uint32_t orbx_wave_min_u32(uint32_t v)
+{
+    ORBX_DPP_SCAN(orbx_op_min_u32, uint32_t, v, 0xffffffffu);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int orbx_wave_max_i32(int v)
+{
+    ORBX_DPP_SCAN(orbx_op_max_i32, int, v, (int)0x80000000);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// inclusive prefix sum over the lanes
+__device__ __forceinline__ int orbx_wave_scan_add_i32(int v)
+{
+    ORBX_DPP_SCAN(orbx_op_add_i32, int, v, 0);
+    return v;
+}
 #endif
 
 hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, const OrbxGeom &g, const OrbxBuffers &b,

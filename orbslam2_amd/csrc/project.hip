@@ -17,8 +17,6 @@
 
 #include "orbx_internal.h"
 
-extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);  // wave-wide minimum (device library)
-extern "C" __device__ int __ockl_wfred_max_i32(int);            // wave-wide maximum
 
 #define PROJ_SKIP 0xffffffffu
 #define PROJ_HISTO 30     // HISTO_LENGTH, src/ORBmatcher.cc:37
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
                         ent[k] = PROJ_SKIP;
                     mine = min(mine, ent[k]);
                 }
-                const uint32_t best = __ockl_wfred_min_u32(mine);
+                const uint32_t best = orbx_wave_min_u32(mine);
                 if (best == PROJ_SKIP)
                     return -1;
                 const int best_d = (int)(best >> 20);
@@ -150,7 +148,7 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
 #pragma unroll
                     for (int k = 0; k < SLOTS; k++)
                         rest = min(rest, ent[k] == best ? PROJ_SKIP : ent[k]);
-                    const uint32_t second = __ockl_wfred_min_u32(rest);
+                    const uint32_t second = orbx_wave_min_u32(rest);
                     // no second candidate: bestLevel2 stays -1 and differs from any level (:118-126)
                     if (second != PROJ_SKIP && (best & 15u) == (second & 15u) &&
                         (float)best_d > __fmul_rn(a.nnratio, (float)(int)(second >> 20)))
@@ -161,7 +159,7 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
                 for (int k = 0; k < SLOTS; k++)
                     if (ent[k] == best)
                         cand = idx[k];
-                return __ockl_wfred_max_i32(cand);
+                return orbx_wave_max_i32(cand);
             };
             int m = -1;
             if (cnt > a.cap)

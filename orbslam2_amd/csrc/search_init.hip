@@ -19,7 +19,6 @@
 
 #include "orbx_internal.h"
 
-extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);  // wave-wide minimum (device library)
 
 #define SFI_COLS 64  // FRAME_GRID_COLS (include/Frame.h:38)
 #define SFI_ROWS 48  // FRAME_GRID_ROWS
@@ -44,7 +43,7 @@ __device__ __forceinline__ int lanes_below64(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-#define SFI_NT 256  // threads that prepare a pair; the first wave then walks it alone
+#define SFI_NT 1024  // threads that prepare a pair; the first wave then walks it alone
 
 __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__restrict__ kp,
                                                     const uint8_t *__restrict__ desc, const int *__restrict__ counts,
@@ -310,12 +309,12 @@ __global__ __launch_bounds__(SFI_NT) void k_search_init(const orbx_keypoint *__r
                     offer((distance(q, c) << 16) | (uint32_t)c);
                 }
         }
-        const uint32_t w1 = __ockl_wfred_min_u32(b1);
+        const uint32_t w1 = orbx_wave_min_u32(b1);
         if (w1 == 0xffffffffu)
             continue;
         // the runner-up is the winner lane's second key or another lane's first (keys are distinct)
         const int old21 = m21[w1 & 0xffffu];  // in flight while the runner-up is found
-        const uint32_t w2 = __ockl_wfred_min_u32(b1 == w1 ? b2 : b1);
+        const uint32_t w2 = orbx_wave_min_u32(b1 == w1 ? b2 : b1);
         const int best = (int)(w1 >> 16);
         const float best2 = w2 == 0xffffffffu ? 2147483648.0f : (float)(int)(w2 >> 16);  // INT_MAX as float
         if (best <= a.th_low && (float)best < best2 * a.ratio) {

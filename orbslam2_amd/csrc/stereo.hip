@@ -12,7 +12,6 @@
 // below 1.5 * 1.4 * median (:694-707).
 #include "orbx_internal.h"
 
-extern "C" __device__ uint32_t __ockl_wfred_min_u32(uint32_t);
 
 struct StereoArgs {
     int nlevels, out_cap, slabL, slabR, band, th_orb;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
                 }
             }
         }
-        best = __ockl_wfred_min_u32(best);
+        best = orbx_wave_min_u32(best);
         // bestDist starts at TH_HIGH and must end below (TH_HIGH + TH_LOW) / 2 (:590, :620)
         if (best != 0xffffffffu && (int)(best >> 16) < a.th_orb) {
             const int iR = best & 0xffffu;
