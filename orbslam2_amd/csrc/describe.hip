@@ -4,7 +4,6 @@
 // assembly :1147-1181 of the reference).
 #include "orbx_internal.h"
 
-extern "C" __device__ int __ockl_wfred_add_i32(int);  // wave-wide integer sum (device library)
 
 // ---------------------------------------------------------------- blur
 
