@@ -34,4 +34,6 @@ timeout -k 10 300 python3 tools/distinctive_rate.py > "$OUT/distinctive_rate.jso
 timeout -k 10 300 python3 tools/bow_rate.py > "$OUT/bow_rate.json" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/voc_rate.py > "$OUT/voc_rate.json" 2>/dev/null || exit 1
 timeout -k 10 300 python3 tools/projection_rate.py > "$OUT/projection_rate.json" 2>/dev/null || exit 1
+timeout -k 10 100 python3 tools/sfi_time.py > "$OUT/sfi_time.txt" 2>/dev/null || exit 1
+timeout -k 10 60 tools/bin/exp_octree > "$OUT/exp_octree.txt" 2>/dev/null || exit 1
 echo collected
