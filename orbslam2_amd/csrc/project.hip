@@ -103,9 +103,17 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
         __syncthreads();
         if (tid >= 64)
             continue;
+        // the staged count and row of source g+1 are read while source g is decided
+        int ncnt = s_cnt[0];
+        uint2 nce = s_ce[0][lane & (PROJ_STAGE - 1)];
         for (int g = 0; g < nsrc; g++) {
             const int s = s0 + g;
-            const int cnt = s_cnt[g];
+            const int cnt = ncnt;
+            const uint2 ce0 = nce;
+            if (g + 1 < nsrc) {
+                ncnt = s_cnt[g + 1];
+                nce = s_ce[g + 1][lane & (PROJ_STAGE - 1)];
+            }
             // one decision, on SLOTS candidates per lane: nearly every window holds at most 32 candidates (one
             // slot, staged in LDS); the four-slot form serves the crowded ones from global memory
             auto decide = [&](auto slots_tag) -> int {
@@ -116,10 +124,8 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
                 for (int k = 0; k < SLOTS; k++)
                     idx[k] = -1, ent[k] = PROJ_SKIP;
                 if constexpr (SLOTS == 1) {
-                    if (lane < cnt) {
-                        const uint2 ce = s_ce[g][lane];
-                        idx[0] = (int)ce.x, ent[0] = ce.y;
-                    }
+                    if (lane < cnt)
+                        idx[0] = (int)ce0.x, ent[0] = ce0.y;
                 } else {
 #pragma unroll
                     for (int k = 0; k < SLOTS; k++) {
@@ -154,12 +160,17 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
                         (float)best_d > __fmul_rn(a.nnratio, (float)(int)(second >> 20)))
                         return -1;
                 }
-                int cand = -1;
+                if constexpr (SLOTS == 1) {
+                    // an entry carries its position in the list, which here is the lane that holds it
+                    return __builtin_amdgcn_readlane(idx[0], (int)((best >> 4) & 63u));
+                } else {
+                    int cand = -1;
 #pragma unroll
-                for (int k = 0; k < SLOTS; k++)
-                    if (ent[k] == best)
-                        cand = idx[k];
-                return orbx_wave_max_i32(cand);
+                    for (int k = 0; k < SLOTS; k++)
+                        if (ent[k] == best)
+                            cand = idx[k];
+                    return orbx_wave_max_i32(cand);
+                }
             };
             int m = -1;
             if (cnt > a.cap)
@@ -170,8 +181,13 @@ __global__ __launch_bounds__(256) void k_proj_assign(const uint8_t *__restrict__
             if (m >= 0) {
                 nmatches++;
                 if (lane == 0) {
+                    // one LDS operation without a return value: nothing waits for it, and the reads of the next
+                    // source come behind it in the wave's order
                     const uint32_t bit = 1u << (m & 31);
-                    taken[m >> 5] = s_blk[g] ? (taken[m >> 5] | bit) : (taken[m >> 5] & ~bit);
+                    if (s_blk[g])
+                        atomicOr(&taken[m >> 5], bit);
+                    else
+                        atomicAnd(&taken[m >> 5], ~bit);
                     feature_match[m] = s;
                 }
                 __builtin_amdgcn_wave_barrier();
