@@ -145,6 +145,16 @@ int orbx_extractor_stage_times(orbx_extractor *ex, float *ms_sum /* ORBX_NSTAGES
 int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, int border, uint8_t *dst, int dst_stride,
                        int *width, int *height);
 
+/* The whole of mvImagePyramid for one frame of the last batch in one round trip (what
+ * ORBextractor::ComputePyramid leaves behind, src/ORBextractor.cc:1191-1221): level l is written as a
+ * dense (w_l+2*border) x (h_l+2*border) image, BORDER_REFLECT_101 frame included, at dst + offsets[l]
+ * with a row stride of w_l+2*border bytes.  orbx_pyramid_layout reports offsets, level sizes (nlevels
+ * entries each; any may be NULL) and the bytes dst must hold.  One device-to-host copy of the frame's
+ * levels and one synchronisation, against two per level through orbx_pyramid_level. */
+int orbx_pyramid_layout(const orbx_extractor *ex, int border, int64_t *offsets, int *widths, int *heights,
+                        int64_t *total_bytes);
+int orbx_pyramid_download(orbx_extractor *ex, int frame, int border, uint8_t *dst, int64_t dst_bytes);
+
 /* Stage output of the last batch, for parity tests.  what: 1 = blurred level (u8, level-sized). */
 int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int level, uint8_t *dst, int dst_stride);
 /* Candidate list of a level before the quadtree (src/ORBextractor.cc:880-890): coordinates

@@ -64,6 +64,8 @@ SIGNATURES = {
     "orbx_extractor_profile": (C.c_int, [_P, C.c_int]),
     "orbx_extractor_stage_times": (C.c_int, [_P, _f32p, _i32p]),
     "orbx_pyramid_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _i32p, _i32p]),
+    "orbx_pyramid_layout": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(C.c_int64)]),
+    "orbx_pyramid_download": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "orbx_debug_level_map": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int]),
     "orbx_debug_candidates": (C.c_int, [_P, C.c_int, C.c_int, _i32p, _i32p, _i32p, C.c_int, _i32p]),
     "orbx_debug_octree": (C.c_int, [C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p,

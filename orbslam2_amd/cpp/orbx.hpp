@@ -25,6 +25,8 @@ inline void check(int rc, const char *where)
     if (rc < 0)
         throw Error(rc, where);
 }
+// data pointer of an optional array: null when the vector is empty
+template <typename T> inline const T *opt(const std::vector<T> &v) { return v.empty() ? nullptr : v.data(); }
 
 class Extractor {
 public:
@@ -62,6 +64,24 @@ public:
         return true;
     }
 
+    // The same call leaving the results in the extractor's own buffers (valid until the next call):
+    // returns the keypoint count, or -1 for an empty image.  For callers that copy once into their own
+    // containers (the cv:: adaptor).
+    int extract_raw(const uint8_t *image, int width, int height, int stride, const orbx_keypoint *&keypoints,
+                    const uint8_t *&descriptors)
+    {
+        if (!image || width <= 0 || height <= 0)
+            return -1;
+        kp_buf_.resize(cap_);
+        desc_buf_.resize((size_t)cap_ * 32);
+        int n = 0;
+        check(orbx_extract(h_, image, width, height, stride, kp_buf_.data(), desc_buf_.data(), cap_, &n),
+              "orbx_extract");
+        keypoints = kp_buf_.data();
+        descriptors = desc_buf_.data();
+        return n;
+    }
+
     // level of the pyramid of the last call with a reflect-101 frame of `border` pixels
     // (mvImagePyramid keeps border 19, src/ORBextractor.cc:1199-1219)
     std::vector<uint8_t> pyramid_level(int level, int border, int &padded_w, int &padded_h)
@@ -72,6 +92,19 @@ public:
         std::vector<uint8_t> out((size_t)padded_w * padded_h);
         check(orbx_pyramid_level(h_, 0, level, border, out.data(), padded_w, nullptr, nullptr), "orbx_pyramid_level");
         return out;
+    }
+
+    // every level of the last call, framed, in one round trip: level l is a dense
+    // (width[l]+2*border) x (height[l]+2*border) image at out.data() + offset[l]
+    void pyramid(int border, std::vector<uint8_t> &out, std::vector<int64_t> &offset, std::vector<int> &width,
+                 std::vector<int> &height)
+    {
+        offset.resize(nlevels_), width.resize(nlevels_), height.resize(nlevels_);
+        int64_t total = 0;
+        check(orbx_pyramid_layout(h_, border, offset.data(), width.data(), height.data(), &total),
+              "orbx_pyramid_layout");
+        out.resize((size_t)total);
+        check(orbx_pyramid_download(h_, 0, border, out.data(), total), "orbx_pyramid_download");
     }
 
     int GetLevels() const { return nlevels_; }
@@ -229,7 +262,6 @@ public:
         match.assign(ns, -1);
         feature_match.assign(keys.size(), -1);
         int32_t nm = 0;
-        auto opt = [](const auto &v) { return v.empty() ? nullptr : v.data(); };
         check(orbx_search_by_projection(h_, keys.data(), desc.data(), opt(uright), opt(taken), (int)keys.size(),
                                         b.min_x, b.max_x, b.min_y, b.max_y, opt(s.valid), s.x.data(), s.y.data(),
                                         s.r.data(), s.min_level.data(), s.max_level.data(), opt(s.xr), s.desc.data(),

@@ -54,6 +54,8 @@ struct orbx_extractor {
     size_t d_stage_bytes;
     uint8_t *h_out;                // pinned staging of whole-batch downloads into pageable memory
     size_t h_out_bytes;
+    uint8_t *h_pyr;                // pinned staging of orbx_pyramid_download (one frame's level slab)
+    size_t h_pyr_bytes;
     float sf[ORBX_MAX_LEVELS], inv[ORBX_MAX_LEVELS], sig2[ORBX_MAX_LEVELS], invsig2[ORBX_MAX_LEVELS];
     int quota[ORBX_MAX_LEVELS];
     OrbxGeom cap_geom;  // geometry of max_width x max_height: sizes every buffer
@@ -339,6 +341,8 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->d_stage_bytes = 0;
     ex->h_out = nullptr;
     ex->h_out_bytes = 0;
+    ex->h_pyr = nullptr;
+    ex->h_pyr_bytes = 0;
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
@@ -426,6 +430,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor *ex)
     if (ex->h_stage) (void)hipHostFree(ex->h_stage);
     if (ex->d_stage) (void)hipFree(ex->d_stage);
     if (ex->h_out) (void)hipHostFree(ex->h_out);
+    if (ex->h_pyr) (void)hipHostFree(ex->h_pyr);
     if (ex->aux_stream) (void)hipStreamDestroy(ex->aux_stream);
     if (ex->own_stream) (void)hipStreamDestroy(ex->own_stream);
     delete ex;
@@ -948,6 +953,86 @@ extern "C" int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, int 
                                   int *width, int *height)
 {
     return download_level(ex, ex ? ex->buf.pyr : nullptr, frame, level, border, dst, dst_stride, width, height);
+}
+
+extern "C" int orbx_pyramid_layout(const orbx_extractor *ex, int border, int64_t *offsets, int *widths, int *heights,
+                                   int64_t *total_bytes)
+{
+    if (!ex || border < 0)
+        return ORBX_E_ARG;
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    int64_t off = 0;
+    for (int l = 0; l < ex->geom.nlevels; l++) {
+        const OrbxLevel &L = ex->geom.lv[l];
+        if (offsets) offsets[l] = off;
+        if (widths) widths[l] = L.w;
+        if (heights) heights[l] = L.h;
+        off += (int64_t)(L.w + 2 * border) * (L.h + 2 * border);
+    }
+    if (total_bytes)
+        *total_bytes = off;
+    return ORBX_OK;
+}
+
+// All levels of one frame with their reflected frames: the frame's part of the level slab comes back in
+// one contiguous copy (plus one for a level 0 that still lies in the caller's frame), one wait, and the
+// host lays the rows out and mirrors the borders.
+extern "C" int orbx_pyramid_download(orbx_extractor *ex, int frame, int border, uint8_t *dst, int64_t dst_bytes)
+{
+    if (!ex || !dst || border < 0)
+        return ORBX_E_ARG;
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    if (frame < 0 || frame >= ex->geom.batch)
+        return ORBX_E_ARG;
+    const OrbxGeom &g = ex->geom;
+    int64_t total = 0;
+    (void)orbx_pyramid_layout(ex, border, nullptr, nullptr, nullptr, &total);
+    if (dst_bytes < total)
+        return ORBX_E_CAPACITY;
+    HIP_TRY(hipSetDevice(ex->device));
+    const OrbxLevel &L0 = g.lv[0];
+    const bool l0_outside = ex->buf.l0.ptr != ex->buf.pyr + L0.off;
+    const size_t l0_bytes = l0_outside ? (size_t)ex->buf.l0.pitch * (L0.h - 1) + L0.w : 0;
+    const size_t need = (size_t)g.slab + l0_bytes;
+    if (ex->h_pyr_bytes < need) {
+        if (ex->h_pyr)
+            HIP_TRY(hipHostFree(ex->h_pyr));
+        ex->h_pyr = nullptr;
+        ex->h_pyr_bytes = 0;
+        HIP_TRY(hipHostMalloc((void **)&ex->h_pyr, need, hipHostMallocDefault));
+        ex->h_pyr_bytes = need;
+    }
+    // with level 0 outside the slab only the levels above it are fetched from the slab
+    const size_t skip = l0_outside && g.nlevels > 1 ? (size_t)g.lv[1].off : 0;
+    if (!l0_outside || g.nlevels > 1)
+        HIP_TRY(hipMemcpyAsync(ex->h_pyr + skip, ex->buf.pyr + (size_t)frame * g.slab + skip, (size_t)g.slab - skip,
+                               hipMemcpyDeviceToHost, ex->stream));
+    if (l0_outside)
+        HIP_TRY(hipMemcpyAsync(ex->h_pyr + g.slab, ex->buf.l0.ptr + (size_t)frame * ex->buf.l0.fstride, l0_bytes,
+                               hipMemcpyDeviceToHost, ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    uint8_t *out = dst;
+    for (int l = 0; l < g.nlevels; l++) {
+        const OrbxLevel &L = g.lv[l];
+        const uint8_t *src = ex->h_pyr + L.off;
+        size_t src_pitch = L.pitch;
+        if (l == 0 && l0_outside)
+            src = ex->h_pyr + g.slab, src_pitch = ex->buf.l0.pitch;
+        const int pw = L.w + 2 * border, ph = L.h + 2 * border;
+        for (int y = 0; y < ph; y++) {
+            const uint8_t *srow = src + (size_t)reflect101(y - border, L.h) * src_pitch;
+            uint8_t *drow = out + (size_t)y * pw;
+            memcpy(drow + border, srow, L.w);
+            for (int i = 1; i <= border; i++) {
+                drow[border - i] = srow[reflect101(-i, L.w)];
+                drow[border + L.w - 1 + i] = srow[reflect101(L.w - 1 + i, L.w)];
+            }
+        }
+        out += (size_t)pw * ph;
+    }
+    return ORBX_OK;
 }
 
 extern "C" int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int level, uint8_t *dst, int dst_stride)

@@ -101,7 +101,7 @@ class ORBextractor:
                                        C.byref(n)), "orbx_extract")
         self._last = (1, w, h)
         if pyramid_border is not None:
-            self.mvImagePyramid = [self.pyramid_level(0, l, pyramid_border) for l in range(self.nlevels)]
+            self.mvImagePyramid = self.pyramid(0, pyramid_border)
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     # ---- batch form ----
@@ -179,6 +179,22 @@ class ORBextractor:
         L.check(self._lib.orbx_pyramid_level(self._h, frame, level, border, L.ptr(out), out.strides[0], None, None),
                 "orbx_pyramid_level")
         return out
+
+    def pyramid(self, frame=0, border=19):
+        """All levels of one frame with their reflect-101 frames in one round trip (orbx_pyramid_download):
+        a list of (h+2*border, w+2*border) arrays, views into one buffer."""
+        nl = self.nlevels
+        offs = np.zeros(nl, np.int64)
+        ws, hs = np.zeros(nl, np.int32), np.zeros(nl, np.int32)
+        total = C.c_int64(0)
+        L.check(self._lib.orbx_pyramid_layout(self._h, border, L.ptr(offs), L.ptr(ws), L.ptr(hs), C.byref(total)),
+                "orbx_pyramid_layout")
+        buf = np.zeros(total.value, np.uint8)
+        L.check(self._lib.orbx_pyramid_download(self._h, frame, border, L.ptr(buf), total.value),
+                "orbx_pyramid_download")
+        return [buf[offs[l]:offs[l] + (ws[l] + 2 * border) * (hs[l] + 2 * border)].reshape(hs[l] + 2 * border,
+                                                                                           ws[l] + 2 * border)
+                for l in range(nl)]
 
     def debug_level_map(self, what, frame, level):
         w, h = self.level_size(frame, level)

@@ -4,7 +4,8 @@
 The reference holds no golden vectors for the ORB front end and cannot be built here (OpenCV is
 absent), so these vectors come from the CPU oracle (oracle/orb_oracle.c) on seeded synthetic frames:
 they pin the oracle against regressions and give the GPU path a committed target.  Small cases are
-stored whole (keypoints, descriptors, per-level counts); the benchmark-sized cases as SHA-256 digests.
+stored whole (keypoints, descriptors, per-level counts); the benchmark-sized cases as SHA-256 digests of
+the keypoint fields plus their descriptor rows.
 Run from the repository root:  python tests/golden/make_golden.py
 """
 import hashlib
@@ -35,11 +36,12 @@ LARGE = [  # name, width, height, variant, nfeatures
 ]
 
 
-def digest(kps, desc):
+def digest(kps, desc=None):
     h = hashlib.sha256()
     for f in ("x", "y", "size", "response", "octave", "class_id"):
         h.update(np.ascontiguousarray(kps[f]).tobytes())
-    h.update(np.ascontiguousarray(desc).tobytes())
+    if desc is not None:
+        h.update(np.ascontiguousarray(desc).tobytes())
     return h.hexdigest()
 
 
@@ -52,6 +54,7 @@ def main():
                             params=np.array([nf, 8, ini, mn], np.int32))
         print(name, len(kps))
     out = {}
+    large_desc = {}
     for name, w, h, var, nf in LARGE:
         img = orbx.synth_image(SEED, w, h, var)
         kps, desc, tr = orc.extract(img, nf, 1.2, 8, 20, 7, trace=True)
@@ -59,10 +62,14 @@ def main():
                      "ncand": [int(v) for v in tr["ncand"]], "nkeep": [int(v) for v in tr["nkeep"]],
                      "image_sha256": hashlib.sha256(img.tobytes()).hexdigest(),
                      "angles_sha256": hashlib.sha256(np.ascontiguousarray(kps["angle"]).tobytes()).hexdigest(),
-                     "sha256": digest(kps, desc)}
+                     "keypoints_sha256": digest(kps), "sha256": digest(kps, desc)}
+        large_desc[name] = desc
         print(name, len(kps))
     with open(os.path.join(HERE, "large_digests.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
+    # the descriptors themselves: a GPU run may differ in a bounded number of bits (device cos/sin), which a
+    # digest cannot express
+    np.savez_compressed(os.path.join(HERE, "large_descriptors.npz"), **large_desc)
     # matcher: top-2 of 64 queries over 5000 rows
     db = orbx.synth_descriptors(11, 5000)
     q = db[::78][:64].copy()

@@ -73,3 +73,16 @@ def test_cpp_host_layer_matches_python_binding():
     psum = int(((pm.astype(np.int64) + 1) * (np.arange(len(pm)) + 1)).sum())
     psum += int(((pfm.astype(np.int64) + 3) * (np.arange(len(pfm)) + 1)).sum())
     assert int(fields["proj"]) == nproj and nproj > 100 and int(fields["pm"]) == psum
+
+
+def test_cv_adaptor_driven_like_frame():
+    """ORB_SLAM2::ORBextractor (orbslam2_amd/cpp/ORBextractor.{h,cc}) called the way src/Frame.cc:62-118, 256-262
+    calls the class it replaces: two extractors in two threads, cv::KeyPoint / cv::Mat outputs, the lazily
+    fetched mvImagePyramid, DescriptorDistance and ComputeStereoMatches as INTEGRATION.md writes them.  The
+    program checks every result against the same call through the C ABI."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_adaptor")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "orbslam2_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for size in (("752", "480"), ("641", "479")):
+        out = subprocess.run([exe, *size], capture_output=True, text=True, env=env, timeout=100)
+        assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr

@@ -24,6 +24,9 @@ def oracle_extract(oracle, img, p, blur_variant=0, trace=False):
     return oracle.extract(img, p["nfeatures"], p["scale"], p["nlevels"], p["ini"], p["minth"], blur_variant, trace)
 
 
+DESC_BIT_TOL = 1e-3  # share of descriptor bits that may differ (cos/sin rounding); observed: none
+
+
 def compare_frame(kg, dg, ko, do):
     assert len(kg) == len(ko)
     for f in ("x", "y", "size", "response", "octave", "class_id"):
@@ -35,7 +38,7 @@ def compare_frame(kg, dg, ko, do):
     assert dang.max() <= 1e-3, dang.max()
     bits = np.unpackbits(dg ^ do).sum()
     frac = bits / (dg.size * 8.0)
-    assert frac <= 1e-3, frac
+    assert frac <= DESC_BIT_TOL, frac
     return frac
 
 
@@ -214,6 +217,10 @@ def test_device_batch_in_place_and_copied(oracle, stride):
         compare_frame(kg, dg, ko, do)
     lev0 = ex.pyramid_level(1, 0)
     assert np.array_equal(lev0, host[1][:, :w])
+    # all levels of a frame in one round trip equal the level-by-level reads (level 0 read in place or copied)
+    for border in (0, 19):
+        for l, got in enumerate(ex.pyramid(2, border)):
+            assert np.array_equal(got, ex.pyramid_level(2, l, border)), (border, l)
 
 
 def test_gpu_reproduces_golden_fixtures():
@@ -234,23 +241,24 @@ def test_gpu_reproduces_golden_fixtures():
         assert list(per_level[0]) == list(g["nkeep"])
         ex.close()
     large = json.load(open(os.path.join(gdir, "large_digests.json")))
+    large_desc = np.load(os.path.join(gdir, "large_descriptors.npz"))
     for name, e in large.items():
         img = orbx.synth_image(e["seed"], e["width"], e["height"], e["variant"])
         ex = orbx.ORBextractor(e["nfeatures"], 1.2, 8, 20, 7, max_width=e["width"], max_height=e["height"])
         kg, dg = ex(img)
         assert len(kg) == e["n"], name
+        # keypoint fields: bit-exact, asserted on their own digest
         h = hashlib.sha256()
         for f in ("x", "y", "size", "response", "octave", "class_id"):
             h.update(np.ascontiguousarray(kg[f]).tobytes())
-        # keypoints are bit-exact; descriptors may differ in a few bits (cos/sin rounding), so the
-        # digest is taken over the keypoint fields only when the descriptor digest differs
-        hk = h.copy()
-        h.update(np.ascontiguousarray(dg).tobytes())
-        if h.hexdigest() != e["sha256"]:
-            ko, do = None, None
-            from oracle import pyoracle as orc
-            ko, do = orc.extract(img, e["nfeatures"], 1.2, 8, 20, 7)
-            compare_frame(kg, dg, ko, do)
+        assert h.hexdigest() == e["keypoints_sha256"], name
+        _, per_level = ex.batch_counts()
+        assert list(per_level[0]) == e["nkeep"], name
+        # descriptors: at most 0.1 % of the bits may differ from the fixture (device cos/sin against the
+        # host's; observed: none)
+        want = large_desc[name]
+        assert want.shape == dg.shape, name
+        assert int(np.unpackbits(dg ^ want).sum()) <= DESC_BIT_TOL * dg.size * 8, name
         ex.close()
 
 
