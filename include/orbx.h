@@ -218,6 +218,22 @@ int orbx_match_top2_device(orbx_matcher *m, const uint8_t *d_queries, int nq, co
 int orbx_match_top2(orbx_matcher *m, const uint8_t *queries, int nq, const uint8_t *db, int64_t ndb,
                     int64_t idx_base, int32_t *best_idx, uint16_t *d1, uint16_t *d2);
 
+/* orbx_match_top2_device for callers that cannot allocate.  It has no counterpart in the reference: it
+ * is for code under HIP stream capture, tight serving loops and harnesses that forbid hipMalloc.  No
+ * handle: the call makes no hipMalloc, hipFree or other allocating call.  The per-chunk partial results,
+ * which the handle form keeps in a buffer it allocates and grows, live in an 8 MB array inside the
+ * library's device code (every GPU the library is used on holds its own copy until the process ends).
+ * Same kernels, same results.  Limit: nq * (number of database chunks) <= 1,048,576 partial results; the
+ * database is cut into at most ceil(ndb / 32736) chunks to fit (2000 queries against 1,000,000 rows need
+ * 510,000), beyond that the call returns ORBX_E_CAPACITY and launches nothing.  device = HIP ordinal (made
+ * current), hip_stream = a hipStream_t (NULL = the default stream); all pointers are device addresses;
+ * asynchronous on that stream.  Calls that overlap on one GPU (two streams, two threads) share the array
+ * and race: serialise them per GPU.  The first call on a device also asks the runtime for the array's
+ * address, so make one call before capturing a stream. */
+int orbx_match_top2_device_noalloc(int device, void *hip_stream, const uint8_t *d_queries, int nq,
+                                   const uint8_t *d_db, int64_t ndb, int64_t idx_base, int32_t *d_best_idx,
+                                   uint16_t *d_d1, uint16_t *d_d2);
+
 /* Merges per-shard top-2 results (nshards arrays of nq entries, shard s at offset s*nq, shards in
  * ascending index order) into the result of one pass over the concatenated database. Host function. */
 int orbx_top2_merge(int nshards, int nq, const int32_t *best_idx, const uint16_t *d1, const uint16_t *d2,

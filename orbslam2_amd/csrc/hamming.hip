@@ -578,3 +578,89 @@ hipError_t orbx_launch_top2_mfma(const uint8_t *d_q, int nq, const uint8_t *d_db
                                               (long long)idx_base, d_best, d_d1, d_d2);
     return hipGetLastError();
 }
+
+// ---- brute-force top-2 for callers that cannot allocate ----
+// The per-chunk partial results of the two kernels above normally live in a buffer the matcher handle
+// allocates and grows.  This entry point keeps them in a file-scope device array instead, so a call
+// makes no hipMalloc / hipFree at all (code under stream capture, serving loops, harnesses that forbid
+// allocation).  Every GPU the library runs on holds its own copy of the array (8 MB) at its own address
+// until the process ends.  `scratch` below is only the host-side stand-in of that array: host code never
+// passes it anywhere; the device address is asked for once per device with hipGetSymbolAddress and kept
+// in g_scratch_ptr.
+#define NOALLOC_ENTRIES (1u << 20)  // uint2 entries: chunks * queries of one call must fit
+#define NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) uint2 scratch[NOALLOC_ENTRIES];
+
+#include <mutex>
+static std::mutex g_scratch_mutex;
+static uint2 *g_scratch_ptr[NOALLOC_MAX_DEVICES];  // per device; null until its first call
+
+// device address of this device's copy of the array; `device` must be current
+static hipError_t scratch_address(int device, uint2 **out)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess)
+            return e;
+        g_scratch_ptr[device] = static_cast<uint2 *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
+extern "C" int orbx_match_top2_device_noalloc(int device, void *hip_stream, const uint8_t *d_queries, int nq,
+                                              const uint8_t *d_db, int64_t ndb, int64_t idx_base,
+                                              int32_t *d_best_idx, uint16_t *d_d1, uint16_t *d_d2)
+{
+    if (!d_queries || nq < 1 || ndb < 0 || (ndb > 0 && !d_db) || !d_best_idx || !d_d1 || !d_d2 || device < 0 ||
+        device >= NOALLOC_MAX_DEVICES || idx_base < 0 || idx_base + ndb > INT32_MAX)
+        return ORBX_E_ARG;
+    if ((size_t)nq > NOALLOC_ENTRIES)
+        return ORBX_E_CAPACITY;
+    if (hipSetDevice(device) != hipSuccess)
+        return ORBX_E_NODEVICE;
+    uint2 *partial = nullptr;
+    hipError_t e = scratch_address(device, &partial);
+    if (e != hipSuccess) {
+        orbx_note_hip_error(e);
+        return ORBX_E_HIP;
+    }
+    // the same kernels and the same choice between them as orbx_match_top2_device; the database is cut
+    // into fewer, longer chunks when the usual cut would not fit the array (the merge is exact for any cut)
+    const bool mfma = nq >= 32;
+    const int max_rows = mfma ? MF_MAX_CHUNK / 32 * 32 : 32768, unit = mfma ? 32 : 4;
+    int chunk_rows = 256, nchunks = 0;
+    if (ndb > 0) {
+        if (mfma)
+            orbx_top2_mfma_chunks(nq, ndb, &chunk_rows, &nchunks);
+        else {
+            const int qblocks = (nq + 255) / 256, want = std::max(1, 4096 / qblocks);
+            int64_t rows = std::max<int64_t>(256, std::min<int64_t>((ndb + want - 1) / want, 32768));
+            chunk_rows = (int)((rows + 3) / 4 * 4);
+            nchunks = (int)((ndb + chunk_rows - 1) / chunk_rows);
+        }
+        const int64_t fit = (int64_t)(NOALLOC_ENTRIES / (unsigned)nq);  // chunks the array has room for (>= 1)
+        if (nchunks > fit) {
+            int64_t rows = (ndb + fit - 1) / fit;
+            rows = (rows + unit - 1) / unit * unit;
+            if (rows > max_rows)
+                return ORBX_E_CAPACITY;  // nq * ceil(ndb / longest chunk) partial results exceed the array
+            chunk_rows = (int)rows;
+            nchunks = (int)((ndb + rows - 1) / rows);
+        }
+    }
+    // Nothing in the array has to start at zero: the first kernel writes entry (chunk, query) for every
+    // chunk and query of this call, and the merge reads exactly those.
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    e = mfma ? orbx_launch_top2_mfma(d_queries, nq, d_db, ndb, idx_base, reinterpret_cast<uint32_t *>(partial), chunk_rows,
+                                     nchunks, d_best_idx, d_d1, d_d2, s)
+             : orbx_launch_top2(d_queries, nq, d_db, ndb, idx_base, reinterpret_cast<uint32_t *>(partial), chunk_rows,
+                                nchunks, d_best_idx, d_d1, d_d2, s);
+    if (e != hipSuccess) {
+        orbx_note_hip_error(e);
+        return ORBX_E_HIP;
+    }
+    return ORBX_OK;
+}

@@ -37,6 +37,7 @@ extern "C" const char *orbx_strerror(int code)
     }
 }
 extern "C" int orbx_last_hip_error(void) { return g_last_hip; }
+void orbx_note_hip_error(hipError_t e) { g_last_hip = (int)e; }
 extern "C" int orbx_version(void) { return 100; }
 
 // ------------------------------------------------------------------ extractor handle

@@ -77,6 +77,16 @@ class ORBmatcher:
                 "orbx_match_top2_device")
 
     @staticmethod
+    def match_top2_device_noalloc(device, hip_stream, d_q, nq, d_db, ndb, idx_base, d_best, d_d1, d_d2):
+        """match_top2_device without a handle and without any allocation (orbx_match_top2_device_noalloc):
+        the partial results live in an array inside the library's device code.  Calls on one GPU must
+        not overlap."""
+        L.check(L.lib().orbx_match_top2_device_noalloc(device, C.c_void_p(hip_stream), C.c_void_p(d_q), nq,
+                                                       C.c_void_p(d_db), ndb, idx_base, C.c_void_p(d_best),
+                                                       C.c_void_p(d_d1), C.c_void_p(d_d2)),
+                "orbx_match_top2_device_noalloc")
+
+    @staticmethod
     def merge_top2(best, d1, d2):
         """Merges per-shard results of shape (nshards, nq) (shards in ascending index order)."""
         best = np.ascontiguousarray(best, np.int32)
