@@ -1406,6 +1406,8 @@ static int stereo_check(const orbx_extractor *left, const orbx_extractor *right)
         a.slab != b.slab || left->geom_w != right->geom_w || left->geom_h != right->geom_h ||
         left->p.scale_factor != right->p.scale_factor)
         return ORBX_E_ARG;  // the two images of a stereo frame share size and extractor settings
+    if (a.out_cap > 65535)
+        return ORBX_E_CAPACITY;  // the row table and the packed best keys hold right-keypoint indices in 16 bits
     return ORBX_OK;
 }
 
