@@ -20,6 +20,10 @@
 // polarities at once with packed 16-bit min/max; suppress non-maxima; append.
 #include "orbx_internal.h"
 
+#ifndef FAST_CUT
+#define FAST_CUT(n)  // measurement hook of tools/exp_fast.hip: leave the kernel after phase n
+#endif
+
 #define IMG_W 96                 // staged bytes per row: columns tx0-16 .. tx0+79 (16-byte pieces)
 #define IMG_X0 16                // staged column of pixel tx0
 #define IMG_H (ORBX_FAST_H + 8)  // 72 staged rows: ty0-4 .. ty0+67
@@ -96,18 +100,21 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
 #pragma unroll
     for (int k = 0; k < 16; k++)
         d[k] = (uint32_t)(__mul24((int)d[k], -65535) + 0x00ff0000);
-    uint32_t m2[16], m4[16];
+    // Arc k holds ring pixels k .. k+8.  Arcs k and k-1 share the eight pixels k .. k+7, so
+    //   min(max_arc(k), max_arc(k-1)) = max(max8(k), min(d[k+8], d[k-1]))
+    // and the even k cover all sixteen arcs: the eight-pixel maxima are needed at even k only.
+    uint32_t m2[8], m4[8];
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        m2[k] = pk_max(d[k], d[(k + 1) & 15]);
+    for (int k = 0; k < 8; k++)
+        m2[k] = pk_max(d[2 * k], d[2 * k + 1]);
 #pragma unroll
-    for (int k = 0; k < 16; k++)
-        m4[k] = pk_max(m2[k], m2[(k + 2) & 15]);
+    for (int k = 0; k < 8; k++)
+        m4[k] = pk_max(m2[k], m2[(k + 1) & 7]);
     uint32_t best = 0xffffffffu;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t m8 = pk_max(m4[k], m4[(k + 4) & 15]);
-        best = pk_min(best, pk_max(m8, d[(k + 8) & 15]));
+    for (int k = 0; k < 8; k++) {
+        const uint32_t m8 = pk_max(m4[k], m4[(k + 2) & 7]);  // pixels 2k .. 2k+7
+        best = pk_min(best, pk_max(m8, pk_min(d[(2 * k + 8) & 15], d[(2 * k + 15) & 15])));
     }
     const int v = t[0];
     const int dark = v - (int)(best & 0xffff);
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             *my_cnt = 0;
         return;
     }
+    FAST_CUT(0);
     const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
     const int lane = threadIdx.x & 63;
     uint32_t *img32 = reinterpret_cast<uint32_t *>(img);
@@ -196,6 +204,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         }
     }
     __syncthreads();
+    FAST_CUT(1);
 
     // ---- compass test, four pixels per thread, on staged rows 3..68 (tile rows -1..64) ----
     const int tm = a.t_low;
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         }
     }
     __syncthreads();
+    FAST_CUT(2);
 
     // ---- full score for the queued pixels ----
     const int nq = qn;
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             sc[r * IMG_W + c] = (uint8_t)A;
     }
     __syncthreads();
+    FAST_CUT(3);
 
     // ---- non-maximum suppression inside the pixel's cell, on the tile proper ----
     // Survivors go to the tile's own list (no global atomics); a later pass concatenates the lists.
