@@ -32,7 +32,9 @@
 #define GRP_W 18                 // words that matter: columns tx0-4 .. tx0+67
 #define SC_W (ORBX_FAST_W + 2)   // 66: tile plus a one-pixel ring
 #define SC_H (ORBX_FAST_H + 2)   // 66: staged rows 3..68
-#define QUEUE_CAP (SC_H * SC_W)
+#define QUEUE_CAP (SC_H * SC_W)   // every pixel of the tile and its ring may pass the compass test
+#define SC_P 72                  // bytes per row of the score map: staged columns 12 .. 83 (the 18 words that matter)
+#define SC_AT(r, c) (((r) - 3) * SC_P + (c) - 4 * GRP_0)  // score of staged row r (3 .. 68), staged column c
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
@@ -145,9 +147,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
                                               FastArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[IMG_H * IMG_W];  // staged pixels
-    __shared__ __attribute__((aligned(16))) uint8_t sc[IMG_H * IMG_W];   // A where it exceeds t_low, else 0 (staged coordinates)
-    __shared__ uint16_t queue[QUEUE_CAP];  // pixels that passed the compass test: staged row<<7 | staged column
-    __shared__ int qn, sn;
+    __shared__ __attribute__((aligned(16))) uint8_t sc[SC_H * SC_P];     // A where it exceeds t_low, else 0
+    // Pixels that passed the compass test (staged row<<7 | staged column), filled from the bottom.  The corners
+    // among them that lie inside the tile are collected from the top of the same array downwards while the
+    // queue is consumed: about 500 entries and 300 corners per tile, so the two meet only on images where
+    // most pixels pass; such a tile visits all its pixels in the suppression pass instead.
+    __shared__ uint16_t queue[QUEUE_CAP];
+    __shared__ int qn, sn, cn;
 
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     uint32_t *sc32 = reinterpret_cast<uint32_t *>(sc);
 
     if (threadIdx.x == 0)
-        qn = 0, sn = 0;
+        qn = 0, sn = 0, cn = 0;
     // a thread keeps one word column (of the 18 that matter) and walks down the rows in steps of 14
     const int g = threadIdx.x % GRP_W, r0 = threadIdx.x / GRP_W;
     const bool walker = threadIdx.x < 14 * GRP_W;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             const int y = ty0 - 4 + r;
             if (walker && r < 3 + SC_H) {
                 const uint32_t *wrow = img32 + r * IMG_WORDS + GRP_0 + g;
-                sc32[r * IMG_WORDS + GRP_0 + g] = 0u;
+                sc32[(r - 3) * (SC_P / 4) + g] = 0u;
                 if (gmask != 0u && (all_valid || (y >= y_lo && y < y_hi))) {
                     const uint32_t vw = wrow[0], upw = wrow[-3 * IMG_WORDS], dnw = wrow[3 * IMG_WORDS];
                     const uint32_t lw = wrow[-1], rw = wrow[1];
@@ -268,13 +274,32 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     FAST_CUT(2);
 
     // ---- full score for the queued pixels ----
+    // About 0.6 of the queued pixels are corners, and only corners inside the tile proper take part in the
+    // suppression pass: they are compacted (ballot, one LDS atomic per wave) so that it runs on full waves.
     const int nq = qn;
-    for (int qi = threadIdx.x; qi < nq; qi += 256) {
-        const int e = queue[qi];
-        const int r = e >> 7, c = e & 127;  // staged row / column
-        const int A = fast_arc_score(&img[r * IMG_W + c]);
-        if (A > tm)
-            sc[r * IMG_W + c] = (uint8_t)A;
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int qi = q0 + threadIdx.x;
+        bool corner = false;
+        int e = 0;
+        if (qi < nq) {
+            e = queue[qi];
+            const int r = e >> 7, c = e & 127;  // staged row / column
+            const int A = fast_arc_score(&img[r * IMG_W + c]);
+            if (A > tm) {
+                sc[SC_AT(r, c)] = (uint8_t)A;
+                // ring pixels belong to a neighbouring tile
+                corner = r >= 4 && r < 4 + ORBX_FAST_H && c >= IMG_X0 && c < IMG_X0 + ORBX_FAST_W;
+            }
+        }
+        const unsigned long long bal = __ballot(corner);
+        if (bal) {
+            int base = 0;
+            if (lane == 0)
+                base = atomicAdd(&cn, __popcll(bal));
+            const int at = QUEUE_CAP - 1 - (__builtin_amdgcn_readfirstlane(base) + lanes_below(bal));
+            if (corner && at >= nq)  // never onto a queue entry: those may not have been read yet
+                queue[at] = (uint16_t)e;
+        }
     }
     __syncthreads();
     FAST_CUT(3);
@@ -284,14 +309,10 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     uint2 *my_list = tile_list + ((size_t)f * a.tiles_per_frame + unit) * ORBX_TILE_CAP;
     uint8_t *flags = cell_flag + (size_t)f * a.cells_per_frame + a.cell_base[lvl];
     const uint32_t wc_magic = a.wc_magic[lvl], hc_magic = a.hc_magic[lvl];
-    for (int qi = threadIdx.x; qi < nq; qi += 256) {
-        const int e = queue[qi];
+    auto suppress = [&](int e) {
         const int r = e >> 7, c = e & 127;
-        const uint8_t *p = &sc[r * IMG_W + c];
+        const uint8_t *p = &sc[SC_AT(r, c)];
         const int A = p[0];
-        // ring pixels belong to a neighbouring tile
-        if (A == 0 || r < 4 || r >= 4 + ORBX_FAST_H || c < IMG_X0 || c >= IMG_X0 + ORBX_FAST_W)
-            continue;
         const int y = ty0 - 4 + r, x = tx0 - IMG_X0 + c;
         // x - 19 < 4096 and cells are 30 .. 60 pixels: the 20-bit reciprocal divides exactly
         const int cj = (int)(((uint32_t)(x - ORBX_CELL_ORG) * wc_magic) >> 20);
@@ -300,8 +321,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         const bool l = x - 1 >= cx0, rr = x + 1 < cx0 + wc;
         const bool u = y - 1 >= cy0, dn = y + 1 < cy0 + hc;
         const int nl = l ? p[-1] : 0, nr = rr ? p[1] : 0;
-        const int ul = l ? p[-IMG_W - 1] : 0, uc = p[-IMG_W], ur = rr ? p[-IMG_W + 1] : 0;
-        const int dl = l ? p[IMG_W - 1] : 0, dc = p[IMG_W], dr = rr ? p[IMG_W + 1] : 0;
+        const int ul = l ? p[-SC_P - 1] : 0, uc = p[-SC_P], ur = rr ? p[-SC_P + 1] : 0;
+        const int dl = l ? p[SC_P - 1] : 0, dc = p[SC_P], dr = rr ? p[SC_P + 1] : 0;
         const int mu = u ? max(max(ul, uc), ur) : 0, md = dn ? max(max(dl, dc), dr) : 0;
         const int m = max(max(nl, nr), max(mu, md));
         if (A > m) {
@@ -313,6 +334,18 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
                                     ((uint32_t)cell << 12) | ((uint32_t)(y - cy0) << 6) | (uint32_t)(x - cx0));
             if (A > a.t_ini)
                 flags[cell] = 1;  // the cell has a corner above iniThFAST
+        }
+    };
+    const int nc = cn;
+    if (nc <= QUEUE_CAP - nq) {
+        for (int i = threadIdx.x; i < nc; i += 256)
+            suppress(queue[QUEUE_CAP - 1 - i]);
+    } else {
+        // the corner list ran into the queue: visit every pixel of the tile
+        for (int i = threadIdx.x; i < ORBX_FAST_W * ORBX_FAST_H; i += 256) {
+            const int r = 4 + i / ORBX_FAST_W, c = IMG_X0 + i % ORBX_FAST_W;
+            if (sc[SC_AT(r, c)])
+                suppress((r << 7) | c);
         }
     }
     __syncthreads();

@@ -426,10 +426,15 @@ def _texture_images(w, h):
     bars[(yy % 37 < 9) & (xx % 11 < 4)] = 0
     bars[(yy % 53 < 3)] = 0
     ramp = np.clip((xx * 255 // max(w - 1, 1)) + (rng.random((h, w)) < 0.002) * 90, 0, 255).astype(np.uint8)
-    return {"board": board, "field": field, "bars": bars, "ramp": ramp}
+    # white noise: most pixels pass the detector's first (four-point) test, far more than its work queue
+    # holds; isolated bright pixels on the densest lattice that keeps every ring clear, (2a, a + 4b): one
+    # pixel in eight is a corner, all with the same response, more than the detector's corner list holds
+    white = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    lattice = np.where((xx % 2 == 0) & ((yy - xx // 2) % 4 == 0), 230, 20).astype(np.uint8)
+    return {"board": board, "field": field, "bars": bars, "ramp": ramp, "white": white, "lattice": lattice}
 
 
-@pytest.mark.parametrize("kind", ["board", "field", "bars", "ramp"])
+@pytest.mark.parametrize("kind", ["board", "field", "bars", "ramp", "white", "lattice"])
 def test_other_image_statistics(oracle, kind):
     w, h = 752, 480
     img = _texture_images(w, h)[kind]
