@@ -93,6 +93,13 @@ def main():
                     help="one instance, stages serialised and profiled inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--frames-resident", type=int, default=768,
+                    help="synthetic frames resident in HBM per GPU; the steps rotate through them (default: a set larger "
+                         "than the 256 MiB Infinity Cache, so that level 0 cannot stay cached between steps)")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true")
+    ap.add_argument("--pcie-only", action="store_true", help="only the host-memory-to-host-memory measurement")
+    ap.add_argument("--pcie-instances", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -126,9 +133,18 @@ def main():
         batch = args.batch
     # synthetic frames, different on every rank, generated on the host and uploaded once
     stride = (w + 63) // 64 * 64  # pitch-aligned rows: the extractor reads the frames in place
-    host = np.zeros((batch, h, stride), np.uint8)
-    for f in range(batch):
+    nres = max(batch, args.frames_resident // batch * batch)
+    host = np.zeros((nres, h, stride), np.uint8)
+
+    def synth(f):
         host[f] = orbx.synth_image(0x0B5EED00 + rank * 100003 + f, w, h, 0, stride=stride)
+
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as pool:
+        list(pool.map(synth, range(nres)))
+    if args.pcie_only:
+        print(json.dumps(pcie_inclusive(orbx, torch, host, w, h, nfeat, local_rank, instances=args.pcie_instances)))
+        return
     frames = torch.from_numpy(host).cuda()
     # A stereo pair batch: left and right images go through separate extractor instances on separate
     # streams, as the reference runs mpORBextractorLeft / mpORBextractorRight in two threads
@@ -143,11 +159,16 @@ def main():
         e.set_stream(st.cuda_stream)
     stream = streams[0]
     ex = exs[0]
+    nwin = nres // batch  # windows of `batch` frames; step s works on window s % nwin
     eyes = [(frames[i * half:(i + 1) * half], min(half, batch - i * half)) for i in range(ninst)]
+    fbytes = h * stride
+    counter = [0]
 
     def step():
+        base = (counter[0] % nwin) * batch * fbytes
+        counter[0] += 1
         for e, (fr, nb) in zip(exs, eyes):
-            e.extract_batch_device(fr.data_ptr(), nb, w, h, stride, h * stride)
+            e.extract_batch_device(fr.data_ptr() + base, nb, w, h, stride, fbytes)
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,11 +207,13 @@ def main():
     launch_frames = eyes[0][1]
 
     if rank != 0:
-        # the sharded matcher measurement needs every rank; a rank that cannot finish it leaves after the
+        # the measurements with a collective need every rank; a rank that cannot finish one leaves after the
         # same limit as rank 0, so that no rank waits in a collective forever
+        if not args.no_config5:
+            guarded(lambda: bench_config5(orbx, torch, dist, rank, world, w, h, nfeat, batch, stride, coll_dev), None,
+                    "config5", True)
         if dist_path and not args.no_hamming:
-            guarded_sharded_hamming(lambda: bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev),
-                                    None)
+            guarded(lambda: bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev), None, "hamming", True)
         if dist_path:
             dist.destroy_process_group()
         return
@@ -225,7 +248,11 @@ def main():
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "extractor_instances": ninst, "nfeatures": nfeat, "nlevels": 8,
+        "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "extractor_instances": ninst,
+                   "frames_resident_per_gpu": nres, "frames_resident_MiB": round(nres * fbytes / 2**20, 1),
+                   "working_set": "steps rotate through the resident frames; a step also writes and reads %.0f MiB of "
+                                  "pyramid and blurred levels" % (batch * 2 * (per_stage_bytes["fast"]) / 2**20),
+                   "nfeatures": nfeat, "nlevels": 8,
                    "scale_factor": 1.2, "ini_th_fast": 20, "min_th_fast": 7, "mean_keypoints_per_frame": n_kp,
                    "parallelism": "frame-batch shards, no collective"},
         "roofline": roofline,
@@ -235,44 +262,54 @@ def main():
                         "%d instances on %d streams, blur overlapped" % (ninst, 2 * ninst),
     }
 
+    if not args.no_config5:
+        out["config5"] = guarded(lambda: bench_config5(orbx, torch, dist if dist_path else None, rank, world, w, h, nfeat,
+                                                       batch, stride, coll_dev), out, "config5", dist_path)
     if not dist_path and not args.no_hamming:
         out["hamming"] = bench_hamming(orbx, torch, stream)
     if dist_path and not args.no_hamming:
         # the frames/s line must survive a failure or a hang of this extra measurement
-        out["hamming"] = guarded_sharded_hamming(
-            lambda: bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev), out)
-    if not dist_path and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(host, w, nfeat, args.cpu_seconds)
-        out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
-    print(json.dumps(out), flush=True)
+        out["hamming"] = guarded(lambda: bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev), out,
+                                 "hamming", True)
     if dist_path:
-        dist.destroy_process_group()
+        dist.destroy_process_group()  # what follows is rank 0's own business
+    del frames
+    if not args.no_pcie:
+        out["pcie_inclusive"] = pcie_inclusive(orbx, torch, host, w, h, nfeat, local_rank, instances=args.pcie_instances)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(host, w, nfeat, args.cpu_seconds)
+        out["speedup_vs_cpu_baseline"] = round(fps / world / out["cpu_baseline"]["value"], 1)
+        out["speedup_vs_cpu_baseline_what"] = "frames/s of one GPU over frames/s of one host core"
+    print(json.dumps(out), flush=True)
 
 
 SHARDED_HAMMING_LIMIT_S = 150
 
 
-def guarded_sharded_hamming(fn, out):
-    """Runs the sharded matcher measurement under a time limit.  An exception becomes an error entry; at
-    the limit (a rank stuck in a collective because another rank failed) rank 0 prints the line it has
-    (`out`, None on other ranks) and every rank leaves the process."""
+def guarded(fn, out, key, multi_rank):
+    """Runs an extra measurement under a time limit.  An exception becomes an error entry.  At the limit (a
+    rank stuck in a collective because another rank failed) rank 0 prints the line it has (`out`, None on
+    other ranks) with an error entry, and every rank leaves the process with a non-zero status: a hang must
+    not look like a successful run."""
     import threading
 
     def bail():
         if out is not None:
-            out["hamming"] = {"error": "sharded matcher measurement did not finish in %d s" % SHARDED_HAMMING_LIMIT_S}
+            out[key] = {"error": "measurement did not finish in %d s" % SHARDED_HAMMING_LIMIT_S}
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(3)
 
-    timer = threading.Timer(SHARDED_HAMMING_LIMIT_S, bail)
-    timer.daemon = True
-    timer.start()
+    timer = threading.Timer(SHARDED_HAMMING_LIMIT_S, bail) if multi_rank else None
+    if timer:
+        timer.daemon = True
+        timer.start()
     try:
         return fn()
     except Exception as exc:
         return {"error": repr(exc)}
     finally:
-        timer.cancel()
+        if timer:
+            timer.cancel()
 
 
 def _committed(name):
@@ -361,17 +398,86 @@ def bench_hamming(orbx, torch, stream):
     hb, h1, h2 = best.cpu().numpy(), d1.cpu().numpy().astype(np.int64), d2.cpu().numpy().astype(np.int64)
     # bit-exact check of a sample of queries against a numpy pass over the whole database
     ok = True
-    for i in range(0, nq, nq // 40):
+    for i in range(0, nq, 10):
         ok = ok and numpy_top2(hq[i], hdb) == (int(hb[i]), int(h1[i]), int(h2[i]))
     accepted = int(m.ratio_test(h1.astype(np.uint16), h2.astype(np.uint16))[1])
     return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
             "accepted_matches": accepted, "ratio": 0.75, "th": 50, "self_check": bool(ok),
-            "self_check_what": "40 of the queries against a numpy single pass over all rows (index, d1, d2)",
+            "self_check_what": "every tenth query against a numpy single pass over all rows (index, d1, d2)",
             "roofline": {"bound": "mfma", "dtype": "fp4", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12, 1),
                          "peak": round(MFMA_F4_MAC_PER_S * 2 / 1e12, 1), "unit": "TFLOP/s",
                          "frac": round(rate * MAC_PER_PAIR / MFMA_F4_MAC_PER_S, 4),
                          "frac_of_measured_mfma_rate": round(rate * MAC_PER_PAIR / MFMA_F4_MAC_MEASURED, 4),
                          "vs_valu_popcount_roofline": round(rate / peak_pairs, 4)}}
+
+
+def bench_config5(orbx, torch, dist, rank, world, w, h, nfeat, block, stride, coll_dev):
+    """Extraction plus SearchForInitialization-style matching (ratio 0.9, window 100, orientation check:
+    src/Tracking.cc:729-730) of every consecutive frame pair of a sequence of world * block frames cut into
+    contiguous blocks, one per rank.  A rank extracts its block plus the first frame of the next block (the
+    halo) and matches the pairs whose first frame it owns: no collective on the data path.  Synthetic
+    sequence: frame t+1 is frame t's scene shifted by 3 pixels (a wider canvas is generated once per rank
+    and windows of it are the frames), so real matches exist."""
+    from orbslam2_amd.sharded import pair_block
+    n = world * block
+    lo, hi_ext, pair_hi = pair_block(n, rank, world)
+    nfr = hi_ext - lo
+    # one canvas per rank wide enough for its frames; global frame t is the window at x = 3 * (t - lo) of the
+    # canvas of the rank that owns t, and the halo frame is rebuilt from the next rank's canvas seed
+    def canvas(r, count):
+        return orbx.synth_image(0x5EC0DE00 + r, w + 3 * count, h, 0)
+    own = canvas(rank, block)
+    host = np.zeros((nfr, h, stride), np.uint8)
+    for i in range(min(nfr, block)):
+        host[i, :, :w] = own[:, 3 * i:3 * i + w]
+    if nfr > block:
+        host[block, :, :w] = canvas(rank + 1, block)[:, :w]
+    dev = torch.from_numpy(host).cuda()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()  # extractor and matcher share one real stream (the null stream would give each its own)
+    ex = orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=nfr,
+                           device=torch.cuda.current_device())
+    ex.set_stream(st.cuda_stream)
+    m = orbx.ORBmatcher(0.9, True, device=torch.cuda.current_device())
+    m.set_stream(st.cuda_stream)
+    ex.extract_batch_device(dev.data_ptr(), nfr, w, h, stride, h * stride)
+    d_kp, d_desc, d_cnt, cap = ex.device_results()
+    npair = pair_hi - lo
+    m12 = torch.zeros((max(npair, 1), cap), dtype=torch.int32, device="cuda")
+    nm = torch.zeros(max(npair, 1), dtype=torch.int32, device="cuda")
+    npd = torch.zeros(max(npair, 1), dtype=torch.int32, device="cuda")
+    bounds = (0.0, float(w), 0.0, float(h))
+
+    def run():
+        ex.extract_batch_device(dev.data_ptr(), nfr, w, h, stride, h * stride)
+        if npair > 0:
+            # frames lo .. lo+npair are the first npair+1 of the batch: pairs (i, i+1), i < npair
+            m.search_for_initialization_batch_device(d_kp, d_desc, d_cnt, cap, npair + 1, 600, bounds, m12.data_ptr(),
+                                                     nm.data_ptr(), npd.data_ptr(), windowSize=100)
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
+    tot = torch.tensor([float(npair), float(nm.sum().item()), float(npd.sum().item()), float(nfr)], dtype=torch.float64,
+                       device=coll_dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    sec = float(el.item()) / reps
+    pairs, matches, dists, extracted = [float(v) for v in tot.tolist()]
+    ex.close()
+    return {"frames": n, "frame_pairs": int(pairs), "frames_extracted_incl_halo": int(extracted),
+            "frames_per_s": round(n / sec, 1), "candidate_pair_distances_per_s": round(dists / sec, 1),
+            "mean_matches_per_pair": round(matches / max(pairs, 1), 1), "ms_per_pass": round(sec * 1e3, 3),
+            "sharding": "contiguous frame blocks, 1-frame halo re-extracted by the owner of the pair, no collective"}
 
 
 def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
@@ -383,31 +489,22 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
     full, q, _ = config4_data(orbx, nq, ndb)
     db = torch.from_numpy(full[lo:hi].copy()).cuda()
     dq = torch.from_numpy(q).cuda()
-    best = torch.zeros(nq, dtype=torch.int32, device="cuda")
-    d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
-    d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
     # the matcher on this rank's GPU: its launches make that device current
     m = orbx.ORBmatcher(0.75, device=torch.cuda.current_device())
-    m.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    def local(qq, base):
-        m.match_top2_device(qq.data_ptr(), nq, db.data_ptr(), hi - lo, base, best.data_ptr(), d1.data_ptr(),
-                            d2.data_ptr())
-        return best, d1, d2
-
-    sm = ShardedMatcher(local, rank, world, device=coll_dev)
+    sm = ShardedMatcher(None, rank, world, device=coll_dev, matcher=m)
     for _ in range(3):
-        res = sm.match(dq, lo)
+        res = sm.match_device(dq, nq, db, hi - lo, lo)
     torch.cuda.synchronize()
     dist.barrier()
     reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
-        res = sm.match(dq, lo)
+        res = sm.match_device(dq, nq, db, hi - lo, lo)
     torch.cuda.synchronize()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     sec = float(dt.item()) / reps
+    res = [res[0].cpu().numpy(), res[1].cpu().numpy().view(np.uint16), res[2].cpu().numpy().view(np.uint16)]
     ok = True
     if rank == 0:
         for i in range(0, nq, nq // 20):
@@ -415,10 +512,70 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
     del full
     rate = nq * ndb / sec
     return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
-            "shards": world, "exchange": "all_gather of 12 B per query and rank, host merge", "self_check": ok,
+            "shards": world, "exchange": "all_gather of 8 B per query and rank into device memory, merge kernel", "self_check": ok,
             "roofline": {"bound": "mfma", "dtype": "fp4", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12 / world, 1),
                          "peak": round(MFMA_F4_MAC_PER_S * 2 / 1e12, 1), "unit": "TFLOP/s per GPU",
                          "frac": round(rate / world * MAC_PER_PAIR / MFMA_F4_MAC_PER_S, 4)}}
+
+
+def pcie_inclusive(orbx, torch, host, w, h, nfeat, device, batch=64, instances=2, rounds=24):
+    """Frames start in host memory and keypoints / descriptors end in host memory: what a caller of
+    operator() on host images pays.  `instances` extractors, each with its own stream, take batches in turn,
+    so that the upload and extraction of one batch overlap the download of another (a stereo Frame runs two
+    extractors, src/Frame.cc:79-82; a frame server runs more).  Never the benchmark's `value`."""
+    import ctypes as C
+
+    from orbslam2_amd import _lib as L
+
+    lib = L.lib()
+    nfr = min(len(host), batch * 4)
+    stride = host.shape[2]
+    res = {"batch": batch, "instances": instances, "frame_bytes": w * h}
+    exs = [orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=batch, device=device)
+           for _ in range(instances)]
+    cap = exs[0].max_keypoints
+    kp = [torch.empty((batch, cap * 28), dtype=torch.uint8).pin_memory() for _ in range(instances)]
+    de = [torch.empty((batch, cap, 32), dtype=torch.uint8).pin_memory() for _ in range(instances)]
+    cnt = [np.zeros(batch, np.int32) for _ in range(instances)]
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            src = torch.from_numpy(host[:nfr]).pin_memory()
+            base, fbytes = src.data_ptr(), h * stride
+        else:
+            src = host[:nfr].copy()
+            base, fbytes = src.ctypes.data, h * stride
+        ptrs = [(C.c_void_p * batch)(*[base + ((b * batch + f) % nfr) * fbytes for f in range(batch)])
+                for b in range(nfr // batch)]
+
+        def submit(i, b):
+            L.check(lib.orbx_extract_batch_host(exs[i]._h, ptrs[b % len(ptrs)], batch, w, h, stride),
+                    "orbx_extract_batch_host")
+
+        def collect(i):
+            L.check(lib.orbx_batch_download_all(exs[i]._h, C.c_void_p(kp[i].data_ptr()), C.c_void_p(de[i].data_ptr()),
+                                                cap, L.ptr(cnt[i])), "orbx_batch_download_all")
+
+        total_kp = 0
+        for timed in (False, True):
+            n = rounds if timed else instances * 2
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for it in range(n):
+                i = it % instances
+                if it >= instances:
+                    collect(i)
+                    total_kp += int(cnt[i].sum()) if timed else 0
+                submit(i, it)
+            for it in range(n, n + instances):
+                collect(it % instances)
+                total_kp += int(cnt[it % instances].sum()) if timed else 0
+            dt = time.perf_counter() - t0
+        fps = rounds * batch / dt
+        res[kind] = {"frames_per_s": round(fps, 1), "h2d_GBps": round(fps * w * h / 1e9, 2),
+                     "d2h_GBps": round(total_kp / dt * 60 / 1e9, 2), "ms_per_batch": round(dt / rounds * 1e3, 3)}
+    for e in exs:
+        e.close()
+    return res
 
 
 def cpu_baseline(host_frames, w, nfeat, budget_s):

@@ -238,6 +238,13 @@ int orbx_match_top2_device_noalloc(int device, void *hip_stream, const uint8_t *
  * ascending index order) into the result of one pass over the concatenated database. Host function. */
 int orbx_top2_merge(int nshards, int nq, const int32_t *best_idx, const uint16_t *d1, const uint16_t *d2,
                     int32_t *out_idx, uint16_t *out_d1, uint16_t *out_d2);
+/* The same merge on the device, for a database sharded over GPUs: shard s's results are the block of
+ * 8*nq bytes at d_blocks + s*shard_stride_bytes holding nq best indices (int32), nq best distances and nq
+ * second distances (uint16 each) -- what orbx_match_top2_device writes when its three output pointers
+ * are block, block + 4*nq and block + 6*nq, and what an all-gather of such blocks lays side by side.
+ * Asynchronous on the matcher's stream. */
+int orbx_top2_merge_shards_device(orbx_matcher *m, int nshards, int nq, const uint8_t *d_blocks,
+                                  int64_t shard_stride_bytes, int32_t *d_best_idx, uint16_t *d_d1, uint16_t *d_d2);
 /* Acceptance rule of src/ORBmatcher.cc:245-249: d1 <= th && (float)d1 < ratio*(float)d2.
  * accept[i] = 1/0; returns the number accepted. Host function. */
 int orbx_ratio_test(int nq, const uint16_t *d1, const uint16_t *d2, int th, float ratio, uint8_t *accept);

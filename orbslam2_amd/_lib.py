@@ -78,6 +78,7 @@ SIGNATURES = {
     "orbx_match_top2_device_noalloc": (C.c_int, [C.c_int, _P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P, _P, _P]),
     "orbx_match_top2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P, _P, _P]),
     "orbx_top2_merge": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "orbx_top2_merge_shards_device": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, _P, _P, _P]),
     "orbx_ratio_test": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_float, _P]),
     "orbx_search_for_initialization": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float,
                                                  C.c_float, C.c_float, _P, C.c_int, C.c_float, C.c_int, _P,

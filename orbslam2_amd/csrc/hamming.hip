@@ -579,6 +579,48 @@ hipError_t orbx_launch_top2_mfma(const uint8_t *d_q, int nq, const uint8_t *d_db
     return hipGetLastError();
 }
 
+// ---- merge of per-shard results on the device ----
+// Each shard's result block is what orbx_match_top2_device wrote for it into one buffer of 8 bytes per
+// query: nq best indices (int32), then nq best distances, then nq second distances (uint16 each); the
+// blocks of all shards lie shard_stride bytes apart in ascending index order (the layout an all-gather
+// of such buffers produces).  One thread per query folds the shards in order with the single-pass rules
+// (strict '<': the lower shard wins ties; the second best is the least of the other firsts and all
+// seconds), exactly as the host function orbx_top2_merge does.
+__global__ __launch_bounds__(256) void k_top2_merge_shards(const uint8_t *__restrict__ blocks, int nshards, int nq,
+                                                           long long shard_stride, int32_t *__restrict__ best,
+                                                           uint16_t *__restrict__ d1, uint16_t *__restrict__ d2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq)
+        return;
+    int b1 = 256, b2 = 256;
+    int32_t bi = -1;
+    for (int s = 0; s < nshards; s++) {
+        const uint8_t *blk = blocks + (size_t)s * shard_stride;
+        const int a = reinterpret_cast<const uint16_t *>(blk + (size_t)4 * nq)[i];
+        const int b = reinterpret_cast<const uint16_t *>(blk + (size_t)6 * nq)[i];
+        if (a < b1) {
+            b2 = b1;
+            b1 = a;
+            bi = reinterpret_cast<const int32_t *>(blk)[i];
+        } else if (a < b2)
+            b2 = a;
+        if (b < b2)
+            b2 = b;
+    }
+    best[i] = bi;
+    d1[i] = (uint16_t)b1;
+    d2[i] = (uint16_t)b2;
+}
+
+hipError_t orbx_launch_top2_merge_shards(const uint8_t *d_blocks, int nshards, int nq, int64_t shard_stride,
+                                         int32_t *d_best, uint16_t *d_d1, uint16_t *d_d2, hipStream_t s)
+{
+    k_top2_merge_shards<<<(nq + 255) / 256, 256, 0, s>>>(d_blocks, nshards, nq, (long long)shard_stride, d_best, d_d1,
+                                                          d_d2);
+    return hipGetLastError();
+}
+
 // ---- brute-force top-2 for callers that cannot allocate ----
 // The per-chunk partial results of the two kernels above normally live in a buffer the matcher handle
 // allocates and grows.  This entry point keeps them in a file-scope device array instead, so a call

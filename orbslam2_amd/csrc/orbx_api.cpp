@@ -601,11 +601,17 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
             pinned = attr.type == hipMemoryTypeHost;
     }
     if (pinned) {
-        // one contiguous copy per frame in the frame's own row layout (strided copies are slow even from
-        // page-locked memory), then the device path: read in place when rows are word aligned, else
-        // repacked by the ingest kernel
+        // Copies in the frames' own row layout (strided copies are slow even from page-locked memory), then
+        // the device path: read in place when rows are word aligned, else repacked by the ingest kernel.
+        // Frames that lie at equal distances in one allocation (a batch tensor) travel as one copy; else one
+        // copy per frame.
         const size_t src_bytes = (size_t)stride_bytes * (height - 1) + width;
-        const size_t fstride = (src_bytes + 255) / 256 * 256;
+        bool even = batch > 1;
+        ptrdiff_t dist = batch > 1 ? images[1] - images[0] : 0;
+        for (int f = 2; f < batch && even; f++)
+            even = images[f] - images[f - 1] == dist;
+        even = even && dist >= (ptrdiff_t)src_bytes && (dist & 3) == 0 && dist <= (ptrdiff_t)src_bytes + (1 << 16);
+        const size_t fstride = even ? (size_t)dist : (src_bytes + 255) / 256 * 256;
         const size_t need = fstride * (size_t)batch;
         if (ex->d_stage_bytes < need) {
             HIP_TRY(hipStreamSynchronize(ex->stream));
@@ -617,9 +623,13 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
             HIP_TRY(hipMalloc((void **)&ex->d_stage, need + 256));
             ex->d_stage_bytes = need;
         }
-        for (int f = 0; f < batch; f++)
-            HIP_TRY(hipMemcpyAsync(ex->d_stage + (size_t)f * fstride, images[f], src_bytes, hipMemcpyHostToDevice,
-                                   ex->stream));
+        if (even)
+            HIP_TRY(hipMemcpyAsync(ex->d_stage, images[0], fstride * (size_t)(batch - 1) + src_bytes,
+                                   hipMemcpyHostToDevice, ex->stream));
+        else
+            for (int f = 0; f < batch; f++)
+                HIP_TRY(hipMemcpyAsync(ex->d_stage + (size_t)f * fstride, images[f], src_bytes, hipMemcpyHostToDevice,
+                                       ex->stream));
         return orbx_extract_batch_device(ex, ex->d_stage, batch, width, height, stride_bytes, (int64_t)fstride);
     }
     // Pageable rows go through a pinned staging buffer in the level-0 layout: one contiguous
@@ -1376,6 +1386,19 @@ extern "C" int orbx_top2_merge(int nshards, int nq, const int32_t *best_idx, con
         out_d1[i] = (uint16_t)b1;
         out_d2[i] = (uint16_t)b2;
     }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_top2_merge_shards_device(orbx_matcher *m, int nshards, int nq, const uint8_t *d_blocks,
+                                             int64_t shard_stride_bytes, int32_t *d_best_idx, uint16_t *d_d1,
+                                             uint16_t *d_d2)
+{
+    if (!m || nshards < 1 || nq < 1 || !d_blocks || !d_best_idx || !d_d1 || !d_d2 ||
+        shard_stride_bytes < (int64_t)8 * nq || (shard_stride_bytes & 3) != 0 ||
+        (reinterpret_cast<uintptr_t>(d_blocks) & 3) != 0)
+        return ORBX_E_ARG;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(orbx_launch_top2_merge_shards(d_blocks, nshards, nq, shard_stride_bytes, d_best_idx, d_d1, d_d2, m->stream));
     return ORBX_OK;
 }
 

@@ -205,5 +205,7 @@ hipError_t orbx_launch_top2_mfma(const uint8_t *d_q, int nq, const uint8_t *d_db
                                  uint16_t *d_d2, hipStream_t s);
 hipError_t orbx_launch_pair_dist(const uint8_t *d_a, const uint8_t *d_b, const int *d_pairs, int n, uint16_t *d_out,
                                  hipStream_t s);
+hipError_t orbx_launch_top2_merge_shards(const uint8_t *d_blocks, int nshards, int nq, int64_t shard_stride,
+                                         int32_t *d_best, uint16_t *d_d1, uint16_t *d_d2, hipStream_t s);
 // records a HIP error code for orbx_last_hip_error (calling thread)
 void orbx_note_hip_error(hipError_t e);

@@ -76,6 +76,12 @@ class ORBmatcher:
                                                  idx_base, C.c_void_p(d_best), C.c_void_p(d_d1), C.c_void_p(d_d2)),
                 "orbx_match_top2_device")
 
+    def merge_top2_shards_device(self, nshards, nq, d_blocks, shard_stride, d_best, d_d1, d_d2):
+        """Merge of per-shard result blocks on the device (orbx_top2_merge_shards_device)."""
+        L.check(self._lib.orbx_top2_merge_shards_device(self._handle(), nshards, nq, C.c_void_p(d_blocks), shard_stride,
+                                                        C.c_void_p(d_best), C.c_void_p(d_d1), C.c_void_p(d_d2)),
+                "orbx_top2_merge_shards_device")
+
     @staticmethod
     def match_top2_device_noalloc(device, hip_stream, d_q, nq, d_db, ndb, idx_base, d_best, d_d1, d_d2):
         """match_top2_device without a handle and without any allocation (orbx_match_top2_device_noalloc):

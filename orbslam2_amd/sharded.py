@@ -28,13 +28,70 @@ def frame_block(n_frames, rank, world):
     return lo, min(lo + per, n_frames)
 
 
+def pair_block(n_frames, rank, world):
+    """Consecutive-frame matching over frame blocks: rank r extracts frames [lo, hi_ext) -- its block plus,
+    when a later frame exists, frame hi as a halo (the next rank's first frame, extracted twice rather than
+    exchanged: 2000 keypoints of 60 bytes are cheaper to recompute than to synchronise) -- and matches the
+    pairs (t, t+1) for t in [lo, pair_hi): every pair whose first frame it owns.  Returns (lo, hi_ext, pair_hi)."""
+    lo, hi = frame_block(n_frames, rank, world)
+    if hi <= lo:
+        return lo, lo, lo
+    return lo, min(hi + 1, n_frames), min(hi, n_frames - 1)
+
+
 class ShardedMatcher:
     """local_top2(queries, idx_base) -> (best int32[nq], d1 uint16[nq], d2 uint16[nq]) as numpy arrays or
     torch tensors: the top-2 of the queries over this rank's shard, indices already global."""
 
-    def __init__(self, local_top2, rank=0, world=1, group=None, device="cpu"):
+    def __init__(self, local_top2, rank=0, world=1, group=None, device="cpu", matcher=None):
         self.local_top2 = local_top2
         self.rank, self.world, self.group, self.device = rank, world, group, device
+        self.matcher = matcher  # an ORBmatcher on this rank's GPU: needed by match_device only
+        self._bufs = {}
+        self._stream = None
+
+    def match_device(self, d_queries, nq, d_db, ndb, idx_base):
+        """Everything on the GPU: the shard's top-2 goes straight into an 8-byte-per-query block, one
+        all-gather (RCCL) lays the blocks of all ranks side by side, one small kernel merges them.  d_queries
+        and d_db are CUDA tensors; returns (best int32, d1 int16, d2 int16) CUDA tensors (views of buffers
+        that the next call overwrites).  With a CPU backend (gloo rehearsal) the blocks travel through host
+        memory, the merge still runs on the GPU."""
+        import torch
+        m = self.matcher
+        if nq not in self._bufs:
+            dev = d_queries.device
+            self._bufs[nq] = (torch.empty(8 * nq, dtype=torch.uint8, device=dev),
+                              torch.empty(self.world * 8 * nq, dtype=torch.uint8, device=dev),
+                              torch.empty(nq, dtype=torch.int32, device=dev),
+                              torch.empty(nq, dtype=torch.int16, device=dev),
+                              torch.empty(nq, dtype=torch.int16, device=dev))
+        blk, allb, best, d1, d2 = self._bufs[nq]
+        # Kernels of the library and torch's collective must share one real stream: handed the null stream,
+        # the matcher would fall back to its own, unordered with torch's.  Work is fenced against the
+        # caller's current stream on both sides.
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=d_queries.device)
+        caller = torch.cuda.current_stream()
+        self._stream.wait_stream(caller)
+        with torch.cuda.stream(self._stream):
+            m.set_stream(self._stream.cuda_stream)
+            p = blk.data_ptr()
+            m.match_top2_device(d_queries.data_ptr(), nq, d_db.data_ptr(), ndb, idx_base, p, p + 4 * nq, p + 6 * nq)
+            if self.world > 1:
+                import torch.distributed as dist
+                if self.device == "cpu":
+                    host = blk.cpu()
+                    parts = torch.empty(self.world * 8 * nq, dtype=torch.uint8)
+                    dist.all_gather(list(parts.chunk(self.world)), host, group=self.group)
+                    allb.copy_(parts)
+                else:
+                    dist.all_gather_into_tensor(allb, blk, group=self.group)
+            else:
+                allb.copy_(blk)
+            m.merge_top2_shards_device(self.world, nq, allb.data_ptr(), 8 * nq, best.data_ptr(), d1.data_ptr(),
+                                       d2.data_ptr())
+        caller.wait_stream(self._stream)
+        return best, d1, d2
 
     def match(self, queries, idx_base):
         import torch

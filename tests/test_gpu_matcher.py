@@ -122,6 +122,47 @@ def test_sharded_merge_equals_single_pass(oracle):
     assert np.array_equal(mb, ob) and np.array_equal(m1, o1) and np.array_equal(m2, o2)
 
 
+def test_device_shard_merge_equals_single_pass(oracle):
+    """The exchange format of the sharded matcher: every shard's top-2 written straight into its 8-byte-per-query
+    block, the blocks side by side as an all-gather leaves them, merged by orbx_top2_merge_shards_device.  Must
+    equal one pass over the whole database (ties to the lower shard, duplicates across shards)."""
+    import torch
+    from orbslam2_amd.sharded import ShardedMatcher, shard_bounds
+    ndb, nq, world = 30011, 501, 5
+    db, q = make_db(ndb, nq, seed=9)
+    db[20000] = db[7]      # the same row in two shards
+    db[25000:25003] = q[3]  # exact matches in the last shard, best and second tie at distance 0
+    m = orbx.ORBmatcher(0.75)
+    d_db, d_q = torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda()
+    blocks = torch.zeros(world * 8 * nq, dtype=torch.uint8, device="cuda")
+    best = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()  # the matcher works on its own stream
+    for r in range(world):
+        lo, hi = shard_bounds(ndb, r, world)
+        p = blocks.data_ptr() + r * 8 * nq
+        m.match_top2_device(d_q.data_ptr(), nq, d_db.data_ptr() + lo * 32, hi - lo, lo, p, p + 4 * nq, p + 6 * nq)
+    m.merge_top2_shards_device(world, nq, blocks.data_ptr(), 8 * nq, best.data_ptr(), d1.data_ptr(), d2.data_ptr())
+    torch.cuda.synchronize()
+    ob, o1, o2 = oracle.match_top2(q, db)
+    assert np.array_equal(best.cpu().numpy(), ob)
+    assert np.array_equal(d1.cpu().numpy().view(np.uint16), o1) and np.array_equal(d2.cpu().numpy().view(np.uint16), o2)
+    # the host merge on the same blocks
+    hb = blocks.cpu().numpy().reshape(world, 8 * nq)
+    hbest = np.stack([hb[r, :4 * nq].view(np.int32) for r in range(world)])
+    h1 = np.stack([hb[r, 4 * nq:6 * nq].view(np.uint16) for r in range(world)])
+    h2 = np.stack([hb[r, 6 * nq:].view(np.uint16) for r in range(world)])
+    mb, m1, m2 = orbx.ORBmatcher.merge_top2(hbest, h1, h2)
+    assert np.array_equal(mb, ob) and np.array_equal(m1, o1) and np.array_equal(m2, o2)
+    # one rank through ShardedMatcher.match_device (no collective): the same path with a world of one
+    sm = ShardedMatcher(None, 0, 1, device="cuda", matcher=m)
+    b, a1, a2 = sm.match_device(d_q, nq, d_db, ndb, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(b.cpu().numpy(), ob) and np.array_equal(a1.cpu().numpy().view(np.uint16), o1)
+    assert np.array_equal(a2.cpu().numpy().view(np.uint16), o2)
+
+
 def test_full_size_properties():
     """Config-4 size (2000 x 1M): checked through properties instead of the CPU loop: every query was
     cut from a known row, so a query with few flipped bits must find it; d1 <= d2; shard sum rule."""
