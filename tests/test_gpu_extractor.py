@@ -50,6 +50,8 @@ def compare_frame(kg, dg, ko, do):
     (1241, 376, KITTI_LOW, 2),
     (752, 480, EUROC_STEREO, 0),
     (333, 217, TUM, 0),
+    (813, 120, TUM, 0),   # level 0: the last cell column starts 6 px before the border and is skipped (:864)
+    (150, 813, TUM, 0),   # the same remainder in y does not skip the row (:853): the 6-against-3 asymmetry
 ])
 def test_stages_and_frame(oracle, w, h, p, variant):
     img = orbx.synth_image(SEED + 7 * variant, w, h, variant)
@@ -69,6 +71,23 @@ def test_stages_and_frame(oracle, w, h, p, variant):
     _, per_level = ex.batch_counts()
     assert list(per_level[0]) == tr["nkeep"]
     compare_frame(kg, dg, ko, do)
+    ex.close()
+
+
+def test_equal_responses_across_a_cell_border(oracle):
+    """Two equally bright pixels side by side: astride a cell border both are candidates (suppression never
+    looks into the neighbouring cell, src/ORBextractor.cc:868-877), inside a cell neither is."""
+    w, h = 176, 112
+    wcell = int(np.ceil(np.float32(w - 32) / int(np.float32(w - 32) / np.float32(30))))
+    b = 19 + wcell
+    img = np.full((h, w), 50, np.uint8)
+    img[40, b - 1:b + 1] = 200
+    img[70, b + 10:b + 12] = 200
+    ex = orbx.ORBextractor(500, 1.2, 1, 20, 7, max_width=w, max_height=h)
+    ex(img)
+    xs, ys, rs = ex.debug_candidates(0, 0)
+    oxs, oys, ors = oracle.level_candidates(img, 20, 7)
+    assert list(zip(xs, ys, rs)) == list(zip(oxs, oys, ors)) == [(b - 17, 24, 149), (b - 16, 24, 149)]
     ex.close()
 
 

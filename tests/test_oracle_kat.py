@@ -477,3 +477,127 @@ def test_search_by_projection_histogram_factor_of_the_key_frame_form():
     assert nm2 == 10 and list(f2) == list(range(n))
     nm0, _, f0 = orc.search_by_projection(*args, src_angle=rot, use_second=False, check_orientation=0)
     assert nm0 == 10 and list(f0) == list(range(n))
+
+
+def test_resize_edge_clamps_known_answers(oracle):
+    """cv::resize INTER_LINEAR (8-bit, 11-bit coefficients) on two small cases worked out by hand.
+    6x4 -> 5x3 (ratio 1.2 in x, 4/3 in y): fx = .1 .3 .5 .7 .9 at sx = 0..4, coefficient pairs
+    (1843,205) (1434,614) (1024,1024) (614,1434) (205,1843); fy = 1/6, 1/2, 5/6 at sy = 0,1,2, pairs
+    (1707,341) (1024,1024) (341,1707).  First pixel: H0 = 10*1843 + 60*205 = 30730, H1 = 0*1843 + 128*205 =
+    26240; (1707*(30730>>4))>>16 = 50, (341*(26240>>4))>>16 = 8; (50 + 8 + 2) >> 2 = 15."""
+    src = np.array([[10, 60, 200, 35, 90, 255], [0, 128, 77, 250, 13, 140], [99, 31, 180, 64, 222, 5],
+                    [240, 17, 150, 201, 48, 111]], np.uint8)
+    want = np.array([[15, 104, 125, 75, 220], [52, 94, 143, 129, 77], [197, 60, 167, 107, 92]], np.uint8)
+    assert np.array_equal(oracle.resize(src, 5, 3), want)
+    # 3x2 -> 5x4 (enlarging: every clamp of the coordinate computation is taken).  Columns: fx = -0.2 -> sx = 0,
+    # weight (2048,0); 0.4 -> (1229,819); 1.0 -> sx = 1, (2048,0); 1.6 -> sx = 1, (819,1229); 2.2 -> sx = 2 = sw-1:
+    # xmax = 4, the column takes S[2]*2048.  Rows: fy = -0.25 -> sy = -1, both rows clamp to row 0 with (512,1536);
+    # 0.25 -> rows 0,1 (1536,512); 0.75 -> rows 0,1 (512,1536); 1.25 -> sy = 1, sy+1 clamps to row 1: (1536,512)
+    # of the same row.  Second pixel of the first row: H = 10*1229 + 200*819 = 176090 for both rows;
+    # (512*(176090>>4))>>16 = 85, (1536*11005)>>16 = 257; (85 + 257 + 2) >> 2 = 86.
+    src = np.array([[10, 200, 90], [250, 40, 160]], np.uint8)
+    want = np.array([[10, 86, 200, 134, 90], [70, 106, 160, 128, 108], [190, 146, 80, 117, 143],
+                     [250, 166, 40, 112, 160]], np.uint8)
+    assert np.array_equal(oracle.resize(src, 5, 4), want)
+
+
+def _cells_literal(oracle, img, ini_th, min_th):
+    """The loop of ORBextractor::ComputeKeyPointsOctTree (src/ORBextractor.cc:826-893) written out literally on
+    top of cv::FAST for one window (pinned above by test_fast_detect_equals_score_definition): candidates in
+    coordinates relative to (16,16), in the order the reference appends them."""
+    h, w = img.shape
+    minB, maxBX, maxBY = 16, w - 16, h - 16
+    width, height = np.float32(maxBX - minB), np.float32(maxBY - minB)
+    nCols, nRows = int(width / np.float32(30)), int(height / np.float32(30))
+    wCell, hCell = int(np.ceil(width / nCols)), int(np.ceil(height / nRows))
+    out = []
+    for i in range(nRows):
+        iniY = minB + i * hCell
+        maxY = iniY + hCell + 6
+        if iniY >= maxBY - 3:
+            continue
+        maxY = min(maxY, maxBY)
+        for j in range(nCols):
+            iniX = minB + j * wCell
+            maxX = iniX + wCell + 6
+            if iniX >= maxBX - 6:
+                continue
+            maxX = min(maxX, maxBX)
+            xs, ys, rs = oracle.fast_detect(img[iniY:maxY, iniX:maxX], ini_th)
+            if len(xs) == 0:
+                xs, ys, rs = oracle.fast_detect(img[iniY:maxY, iniX:maxX], min_th)
+            out += [(int(x) + j * wCell, int(y) + i * hCell, int(r)) for x, y, r in zip(xs, ys, rs)]
+    return out, wCell, hCell, nCols, nRows
+
+
+def test_cell_grid_literal_loop_and_plateau_across_a_cell_border(oracle):
+    """Per-cell FAST: the candidate list equals the literal cell loop, including a width (813) at which the last
+    cell column starts 6 pixels before the border and is skipped by the `iniX >= maxBorderX-6` rule while the
+    same remainder would not skip a row (`iniY >= maxBorderY-3`), and an image that is mirror-symmetric about a
+    cell border, where two equal responses face each other across the border and both survive (non-maximum
+    suppression never looks into the neighbouring cell), while the same pair inside a cell suppresses itself."""
+    rng = np.random.default_rng(11)
+    for (w, h) in [(813, 100), (200, 813), (176, 144)]:
+        img = np.full((h, w), 128, np.uint8)
+        for _ in range(w * h // 250):
+            x, y = rng.integers(0, w - 4), rng.integers(0, h - 4)
+            img[y:y + rng.integers(3, 30), x:x + rng.integers(3, 30)] = rng.integers(0, 256)
+        img = np.clip(img.astype(int) + rng.integers(-3, 4, img.shape), 0, 255).astype(np.uint8)
+        want, wCell, hCell, nCols, nRows = _cells_literal(oracle, img, 20, 7)
+        xs, ys, rs = oracle.level_candidates(img, 20, 7)
+        assert list(zip(xs.tolist(), ys.tolist(), rs.tolist())) == want and len(want) > 50
+        if w == 813:
+            assert 16 + (nCols - 1) * wCell >= (w - 16) - 6  # the last column is the skipped one
+    # Two equally bright pixels side by side on a flat background: each sees sixteen darker ring pixels, so both
+    # are corners with the same response.  Astride the border between the first two cell columns (detect regions
+    # [19, 19+wCell) and [19+wCell, ...)) both survive, each alone in its cell; ten columns further, inside one
+    # cell, each has a neighbour that is not smaller and neither survives.
+    w, h = 176, 112
+    _, wCell, hCell, _, _ = _cells_literal(oracle, np.zeros((h, w), np.uint8), 20, 7)
+    b = 19 + wCell
+    img = np.full((h, w), 50, np.uint8)
+    img[40, b - 1:b + 1] = 200
+    img[70, b + 10:b + 12] = 200
+    assert (40 - 19) // hCell == (40 - 19 + 1) // hCell and (b + 11 - 19) // wCell == (b + 10 - 19) // wCell
+    want, *_ = _cells_literal(oracle, img, 20, 7)
+    xs, ys, rs = oracle.level_candidates(img, 20, 7)
+    got = list(zip(xs.tolist(), ys.tolist(), rs.tolist()))
+    assert got == want
+    assert got == [(b - 1 - 16, 40 - 16, 149), (b - 16, 40 - 16, 149)]  # response = A - 1 = 150 - 1
+
+
+def test_brief_rounds_half_to_even(oracle):
+    """computeOrbDescriptor (src/ORBextractor.cc:128-169) rounds the rotated sample offsets with cvRound, i.e. to
+    the nearest integer with ties to even.  At 30 degrees the float sine is exactly 0.5, so pattern points with
+    y = 0 and odd x land on a tie: point (1,0) of test 31 has row offset 0.5 -> 0 (not 1), point (-9,0) of test
+    15 has row offset -4.5 -> -4 (not -5).  An independent restatement in float32 with np.rint must equal the
+    oracle's descriptor, and a half-away-from-zero variant of it must differ, on an image built for that."""
+    import re
+    pat = [int(v) for v in re.findall(r"-?\d+", open("orbslam2_amd/csrc/brief_pattern.inc").read().split("\n", 1)[1])]
+    f32 = np.float32
+    rad = f32(f32(30.0) * f32(np.pi / f32(180.0)))
+    a, b = f32(np.cos(np.float64(rad))), f32(np.sin(np.float64(rad)))
+    assert b == f32(0.5)
+    assert pat[4 * 31:4 * 31 + 2] == [1, 0] and pat[4 * 15:4 * 15 + 2] == [-9, 0]
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, size=(41, 41), dtype=np.uint8)
+    # make the two tied samples decide their tests: the tie-to-even pixel bright, the half-away pixel dark
+    img[20 + 0, 20 + 1], img[20 + 1, 20 + 1] = 0, 255
+    img[20 - 4, 20 - 8], img[20 - 5, 20 - 8] = 0, 255
+
+    def describe(rounding):
+        d = np.zeros(32, np.uint8)
+        for t in range(256):
+            v = []
+            for px, py in (pat[4 * t:4 * t + 2], pat[4 * t + 2:4 * t + 4]):
+                row = f32(f32(px) * b) + f32(f32(py) * a)
+                col = f32(f32(px) * a) - f32(f32(py) * b)
+                v.append(int(img[20 + int(rounding(row)), 20 + int(rounding(col))]))
+            d[t // 8] |= int(v[0] < v[1]) << (t % 8)
+        return d
+
+    even = describe(np.rint)
+    away = describe(lambda x: np.sign(x) * np.floor(np.abs(x) + f32(0.5)))
+    got = oracle.brief_descriptor(img, 20, 20, 30.0)
+    assert np.array_equal(got, even)
+    assert not np.array_equal(even, away)
