@@ -236,13 +236,20 @@ struct DescArgs {
     float scale[ORBX_MAX_LEVELS];
 };
 
-#define DESC_SLOTS 64  // keypoint slots per workgroup (16 per wave)
+// Keypoints per wave, one after the other (the next one's window in flight while the current one is computed).
+// A frame's 2000 keypoints then spread over 125 workgroups instead of 32, so fewer frames are in flight on an
+// XCD at a time and more of a frame's window rows are still in its L2 when the next keypoint wants them:
+// 16 -> 4 took the kernel from 0.088 to 0.075 ms per 64 KITTI frames (8: 0.077, 2: 0.083).
+#ifndef DESC_KPW
+#define DESC_KPW 4
+#endif
+#define DESC_SLOTS (4 * DESC_KPW)  // keypoint slots per workgroup
 #define PAT_ROWS 31    // orientation patch: rows y-15 .. y+15
 #define PAT_WORDS 9    // 36 staged bytes per row from the aligned word at or below x-15
 #define BLP_ROWS 37    // descriptor window on the blurred level: rows y-18 .. y+18
 #define BLP_WORDS 11   // 44 staged bytes per row from the aligned word at or below x-18
 
-// One workgroup per 64 consecutive output slots of a frame, 16 keypoints per wave.  For each
+// One workgroup per DESC_SLOTS consecutive output slots of a frame, DESC_KPW keypoints per wave.  For each
 // keypoint the wave copies the two windows it needs into LDS with aligned word loads, all issued
 // before the first use (the gathers would otherwise be a chain of dependent global loads), then
 // sums the patch moments, and later samples the 256 tests, from LDS.  In between, one thread per
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ int s_first[ORBX_MAX_LEVELS + 1];
     __shared__ float s_angle[DESC_SLOTS], s_ca[DESC_SLOTS], s_sa[DESC_SLOTS];
     __shared__ int s_m01[DESC_SLOTS], s_m10[DESC_SLOTS];  // patch moments of the block's keypoints
-    __shared__ int2 s_quad[4][16][16];                    // per wave and keypoint: the moments summed over each quad of lanes
+    __shared__ int2 s_quad[4][DESC_KPW][16];                    // per wave and keypoint: the moments summed over each quad of lanes
     __shared__ uint32_t s_win[4][BLP_ROWS * BLP_WORDS];  // per wave; the smaller patch reuses it
     __shared__ uint32_t s_xy[DESC_SLOTS];                // level coordinates of the block's keypoints
     __shared__ int s_lvl[DESC_SLOTS], s_ki[DESC_SLOTS];  // their level and index into the kept arrays
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     }
     __syncthreads();
     // everything a window fetch needs comes from LDS: no global load sits in front of it
-    const int nmine = min(16, total - (base + wv * 16));  // keypoints of this wave (may be <= 0)
+    const int nmine = min(DESC_KPW, total - (base + wv * DESC_KPW));  // keypoints of this wave (may be <= 0)
 
     // ---- IC_Angle: lanes 0..30 take columns u=-15..15 of rows v = 0,2,4.., lanes 32..62 of rows 1,3,5.. ----
     // The window of keypoint i+1 is fetched into registers while keypoint i is summed.
@@ -355,9 +362,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         }
     }
     if (nmine > 0)
-        fetch_patch(base + wv * 16);
+        fetch_patch(base + wv * DESC_KPW);
     for (int i = 0; i < nmine; i++) {
-        const int ls = wv * 16 + i;
+        const int ls = wv * DESC_KPW + i;
         const int ox = ox_next;
 #pragma unroll
         for (int j = 0; j < 5; j++)
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             const int2 p = s_quad[wv][lane][k];
             m10 += p.x, m01 += p.y;
         }
-        s_m01[wv * 16 + lane] = m01, s_m10[wv * 16 + lane] = m10;
+        s_m01[wv * DESC_KPW + lane] = m01, s_m10[wv * DESC_KPW + lane] = m10;
     }
     __syncthreads();
     // the angles of the block's keypoints, one thread each (inside the loop every lane of a wave would
@@ -442,9 +449,9 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
                          : 0u;
     };
     if (nmine > 0)
-        fetch_window(base + wv * 16);
+        fetch_window(base + wv * DESC_KPW);
     for (int i = 0; i < nmine; i++) {
-        const int ls = wv * 16 + i, slot = base + ls;
+        const int ls = wv * DESC_KPW + i, slot = base + ls;
         const int ox = ox_next;
         __builtin_amdgcn_wave_barrier();  // the previous keypoint's samples are read before this overwrite
 #pragma unroll
