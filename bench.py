@@ -32,10 +32,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-# INT32 vector rate: 256 CUs x 64 lanes per clock x 2.4 GHz (v_xor_b32 / v_bcnt_u32_b32 measured at 36.0e12 per
-# second sustained, tools/ubench_popcount.hip); one 256-bit pair = 8 XOR + 8 popcount-accumulate
+# Vector-ALU issue rates measured by tools/ubench_valu.hip (profiles/r02/ubench_valu.txt), chip-wide, in
+# wave-instructions per second with 8 waves per SIMD: packed 16-bit min/max/add, byte permute / align, 24-bit
+# multiply-add, dot products, popcount, 3-input and compare / select instructions issue at 0.59e12 (one per 4
+# clocks and SIMD); 32-bit add / sub / and / or / xor / shift right, f32 add / mul / fma and moves at about 1.0e12.
+VALU_WAVE_INSTR_PER_S_SLOW = 0.59e12
+VALU_WAVE_INSTR_PER_S_FAST = 1.0e12
+# INT32 lane rate that the popcount roofline of the matcher is quoted on: 256 CUs x 64 lanes per clock x 2.4 GHz;
+# one 256-bit pair = 8 XOR + 8 popcount-accumulate
 VALU_LANE_OPS_PER_S = 256 * 64 * 2.4e9
-VALU_LANE_OPS_MEASURED = 36.0e12
 OPS_PER_PAIR = 16
 # The top-2 kernel runs on the matrix cores for 32 or more queries: a pair is 256 FP4 multiply-adds of
 # v_mfma_scale_f32_32x32x64_f8f6f4 (dense FP4 peak: twice the fp8 rate = 2048 MAC per clock and SIMD, 1024 SIMDs,
@@ -234,14 +239,18 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel_ms_per_launch": round(stage_ms[dom], 4),
                 "algorithmic_bytes_per_launch": dom_bytes,
-                "limiter": "vector-ALU issue (integer), not HBM: see valu_* fields",
+                "limiter": "vector-ALU issue and LDS / barrier latency, not HBM: see valu_* fields",
                 "pipeline_achieved_GBs": round(fps / world * frame_bytes / 1e9, 2),
                 "pipeline_frac": round(fps / world * frame_bytes / 1e9 / HBM_PEAK_GBS, 5)}
     valu = committed_valu(single[dom], args.workload, launch_frames)
     if valu is not None and dom_s > 0:
         roofline["valu_wave_instr_per_launch"] = valu
-        roofline["valu_lane_ops_per_s"] = round(valu * 64 / dom_s / 1e12, 3)
-        roofline["valu_frac_of_measured_issue_rate"] = round(valu * 64 / dom_s / VALU_LANE_OPS_MEASURED, 4)
+        roofline["valu_wave_instr_per_s"] = round(valu / dom_s / 1e12, 4)
+        roofline["valu_issue_ceilings_T_wave_instr_per_s"] = {
+            "packed_16bit_perm_mad_dot_3input": VALU_WAVE_INSTR_PER_S_SLOW / 1e12,
+            "add_sub_logic_f32": VALU_WAVE_INSTR_PER_S_FAST / 1e12,
+            "source": "tools/ubench_valu.hip, profiles/r02/ubench_valu.txt"}
+        roofline["valu_frac_of_slow_class_ceiling"] = round(valu / dom_s / VALU_WAVE_INSTR_PER_S_SLOW, 4)
 
     out = {
         "metric": "ORB frames/s @KITTI 1241x376 2000 kp (1/8 GPU); Hamming matches/s; % roofline",
@@ -274,6 +283,8 @@ def main():
     if dist_path:
         dist.destroy_process_group()  # what follows is rank 0's own business
     del frames
+    for e in exs:
+        e.close()  # their streams would share the few hardware queues with those of the next measurement
     if not args.no_pcie:
         out["pcie_inclusive"] = pcie_inclusive(orbx, torch, host, w, h, nfeat, local_rank, instances=args.pcie_instances)
     if not args.no_cpu_baseline:

@@ -167,19 +167,42 @@ KERNEL(alignbit_b32, I_ALIGNBIT)
 KERNEL(max_u16_sdwa, I_SDWA_MAX)
 KERNEL(add_u32_sdwa, I_ADD_SDWA)
 
+// mixes of the two issue classes: whole rounds (eight independent chains) of one instruction, then of another
+#define KERNEL_MIX(NAME, SEQ)                                                                          \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, long long *clk, uint32_t seed, int iters) \
+    {                                                                                                  \
+        uint32_t r0 = seed + threadIdx.x, r1 = r0 * 3u, r2 = r0 * 5u, r3 = r0 * 7u, r4 = r0 * 11u, r5 = r0 * 13u, \
+                 r6 = r0 * 17u, r7 = r0 * 19u;                                                         \
+        const uint32_t x = seed * 0x9E3779B9u + threadIdx.x, y = 0x07050301u ^ (seed & 0x03030303u);   \
+        const uint32_t sc = seed * 77u;                                                                \
+        const long long t0 = __builtin_amdgcn_s_memtime();                                             \
+        for (int it = 0; it < iters; it++) {                                                           \
+            SEQ                                                                                        \
+        }                                                                                              \
+        const long long t1 = __builtin_amdgcn_s_memtime();                                             \
+        out[blockIdx.x * 256 + threadIdx.x] = r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7;                   \
+        if ((threadIdx.x & 63) == 0)                                                                   \
+            clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                        \
+    }
+KERNEL_MIX(mix_1add_1pkmax, ROUND(I_ADD) ROUND(I_PKMAX) ROUND(I_ADD) ROUND(I_PKMAX) ROUND(I_ADD) ROUND(I_PKMAX) ROUND(I_ADD) ROUND(I_PKMAX))
+KERNEL_MIX(mix_3add_1pkmax, ROUND(I_ADD) ROUND(I_XOR) ROUND(I_SUB) ROUND(I_PKMAX) ROUND(I_ADD) ROUND(I_XOR) ROUND(I_SUB) ROUND(I_PKMAX))
+KERNEL_MIX(mix_1and_1perm, ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM))
+
 typedef void (*kern_t)(uint32_t *, long long *, uint32_t, int);
 struct Entry {
     const char *name;
     kern_t fn;
+    int per_op;  // instructions per macro expansion
 };
-#define E(NAME) {#NAME, k_##NAME}
+#define E(NAME) {#NAME, k_##NAME, 1}
 static const Entry entries[] = {E(fma_f32),      E(add_u32),      E(xor_b32),      E(xor_b32_sgpr), E(bcnt_u32_b32),
                                 E(pk_max_u16),   E(pk_min_u16),   E(pk_add_u16),   E(pk_sub_i16),   E(pk_mul_lo_u16),
                                 E(perm_b32),     E(alignbyte_b32), E(mad_u32_u24), E(mad_i32_i24),  E(mul_u32_u24),
                                 E(mul_lo_u32),   E(dot4_u32_u8),  E(dot2_u32_u16), E(max3_u32),     E(med3_i32),
                                 E(min_u32),      E(and_or_b32),   E(lshl_or_b32),  E(cndmask_b32),  E(sad_u8),
                                 E(msad_u8),      E(bfe_u32),
-    E(and_b32), E(or_b32), E(sub_u32), E(subrev_u32), E(lshlrev_b32), E(lshrrev_b32), E(max_f32), E(min_f32), E(mul_f32), E(add_f32), E(max_u32), E(max_i32), E(pk_max_f16), E(pk_min_f16), E(pk_add_f16), E(pk_fma_f16), E(pk_max_i16), E(max_f16), E(max_u16), E(add_u16), E(cvt_f32_ubyte0), E(mov_b32), E(max3_f32), E(min3_f32), E(med3_f32), E(add3_u32), E(or3_b32), E(lshl_add_u32), E(cndmask_sgpr), E(cmp_lt_u32), E(pk_lshlrev_b16), E(bfi_b32), E(alignbit_b32), E(max_u16_sdwa), E(add_u32_sdwa)};
+    E(and_b32), E(or_b32), E(sub_u32), E(subrev_u32), E(lshlrev_b32), E(lshrrev_b32), E(max_f32), E(min_f32), E(mul_f32), E(add_f32), E(max_u32), E(max_i32), E(pk_max_f16), E(pk_min_f16), E(pk_add_f16), E(pk_fma_f16), E(pk_max_i16), E(max_f16), E(max_u16), E(add_u16), E(cvt_f32_ubyte0), E(mov_b32), E(max3_f32), E(min3_f32), E(med3_f32), E(add3_u32), E(or3_b32), E(lshl_add_u32), E(cndmask_sgpr), E(cmp_lt_u32), E(pk_lshlrev_b16), E(bfi_b32), E(alignbit_b32), E(max_u16_sdwa), E(add_u32_sdwa),
+    E(mix_1add_1pkmax), E(mix_3add_1pkmax), E(mix_1and_1perm)};
 
 int main(int argc, char **argv)
 {
@@ -218,10 +241,10 @@ int main(int argc, char **argv)
                         s += (double)clk[i];
                     // a SIMD holds wps waves; while they run together it issues wps * ops instructions
                     // in the time one of them takes
-                    cyc = s / (blocks * 4) / ((double)iters * OPS_PER_ITER) / wps;
+                    cyc = s / (blocks * 4) / ((double)iters * OPS_PER_ITER * en.per_op) / wps;
                 }
             }
-            const double winstr = (double)blocks * 4 * iters * OPS_PER_ITER;
+            const double winstr = (double)blocks * 4 * iters * OPS_PER_ITER * en.per_op;
             printf("  %d: %5.2f | %6.3f", wps, cyc, winstr / (best_ms * 1e-3) / 1e12);
         }
         printf("\n");
