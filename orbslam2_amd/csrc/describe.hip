@@ -197,9 +197,49 @@ hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
 // ---------------------------------------------------------------- orientation + descriptor
 
 // 512 sample points of the rBRIEF test table, (x,y) int8 pairs, point-major
-__constant__ __attribute__((aligned(16))) int8_t c_pattern[1024] = {
+constexpr int8_t k_pattern[1024] = {
 #include "brief_pattern.inc"
 };
+// the 256 tests as floats (x0, y0, x1, y1): a lane reads the four it evaluates with four 16-byte loads
+struct PatternF {
+    float v[1024];
+};
+constexpr PatternF make_pattern_f()
+{
+    PatternF t{};
+    for (int i = 0; i < 1024; i++)
+        t.v[i] = (float)k_pattern[i];
+    return t;
+}
+__constant__ __attribute__((aligned(16))) PatternF c_pattern_f = make_pattern_f();
+
+// Weights of the orientation patch, one signed byte per pixel, for the words a wave holds in registers.
+// Lanes 0 .. 62 of register j hold word i = lane + 63 * j of the patch rows (9 words each, row i / 9,
+// v = row - 15); once shifted to start at x - 15 the word's bytes are u = 4 * (i % 9) + b - 15.
+// wu holds u, wv holds v, both 0 outside the circular patch, in a 32nd row and in lane 63.
+#define PAT_REGS 5
+struct PatchWeights {
+    uint32_t wu[PAT_REGS][64], wv[PAT_REGS][64];
+};
+constexpr PatchWeights make_patch_weights()
+{
+    constexpr int UMAX[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    PatchWeights t{};
+    for (int j = 0; j < PAT_REGS; j++)
+        for (int l = 0; l < 63; l++) {
+            const int i = l + 63 * j, v = i / 9 - 15;
+            for (int b = 0; b < 4; b++) {
+                const int u = 4 * (i % 9) + b - 15;
+                const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
+                if (av <= 15 && au <= UMAX[av]) {
+                    t.wu[j][l] |= (uint32_t)(u & 0xff) << (8 * b);
+                    t.wv[j][l] |= (uint32_t)(v & 0xff) << (8 * b);
+                }
+            }
+        }
+    return t;
+}
+__constant__ PatchWeights c_patch_w = make_patch_weights();
 // half-width of the circular patch at each |row| (umax, src/ORBextractor.cc:483-505):
 // 15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3
 
@@ -245,17 +285,53 @@ struct DescArgs {
 #endif
 #define DESC_SLOTS (4 * DESC_KPW)  // keypoint slots per workgroup
 #define PAT_ROWS 31    // orientation patch: rows y-15 .. y+15
-#define PAT_WORDS 9    // 36 staged bytes per row from the aligned word at or below x-15
+#define PAT_WORDS 9    // 36 fetched bytes per row from the aligned word at or below x-15
 #define BLP_ROWS 37    // descriptor window on the blurred level: rows y-18 .. y+18
 #define BLP_WORDS 11   // 44 staged bytes per row from the aligned word at or below x-18
+#define BLP_REGS 7     // window words per lane
+#define BLP_SLOTS (64 * BLP_REGS)  // words of a wave's window buffer
 
-// One workgroup per DESC_SLOTS consecutive output slots of a frame, DESC_KPW keypoints per wave.  For each
-// keypoint the wave copies the two windows it needs into LDS with aligned word loads, all issued
-// before the first use (the gathers would otherwise be a chain of dependent global loads), then
-// sums the patch moments, and later samples the 256 tests, from LDS.  In between, one thread per
-// keypoint evaluates cos/sin in double precision (once per keypoint instead of once per lane).
-// The staged rows may run a few bytes past the image width: that stays inside the level slabs,
+// One workgroup per DESC_SLOTS consecutive output slots of a frame, DESC_KPW keypoints per wave.  A
+// keypoint is the same for all lanes of its wave, so the start of its windows is a scalar address and
+// a lane adds only row * pitch + 4 * word.  The windows are fetched as aligned words, 9 or 11 to a row
+// from the word at or below x - 15 or x - 18: the address unit takes a cycle per 64-byte line an
+// instruction touches, but four times that for words at odd byte addresses, and it is the unit a
+// wider or unaligned fetch keeps busy longest.
+// Orientation: the lane keeps its words of the 31 x 36 patch in registers, shifts each to start at
+// x - 15 with the next word from its neighbour lane, and takes two signed 4 x 8-bit dot products
+// with constant weights, u and v of the circular patch (0 outside): the sums of u * (I - 128) and
+// v * (I - 128) are m10 and m01, because u and v sum to 0 over the patch.
+// In between, one thread per keypoint evaluates cos/sin in double precision (once per keypoint instead
+// of once per lane).  Descriptor: the wave copies the 37 x 44 window into LDS and each lane samples four
+// tests.  The loads of keypoint i+1 are in flight while keypoint i is computed.
+// The fetched rows may run a few bytes past the image width: that stays inside the level slabs,
 // which are allocated with slack behind the last level.
+// measurement hook: with DESC_EXP_ROWMASK=m a window row r reads image row r & ~m (fewer cache lines, wrong results)
+#ifdef DESC_EXP_ROWMASK
+#define DESC_EXP_ROW(r) ((r) & ~(uint32_t)DESC_EXP_ROWMASK)
+#else
+#define DESC_EXP_ROW(r) (r)
+#endif
+#ifdef DESC_STAMPS
+// phase stamps of sampled workgroups (measurement builds only, tools/desc_stamps.py)
+__device__ unsigned long long g_desc_stamps[1024][8];
+__device__ unsigned int g_desc_nstamp;
+extern "C" int orbx_debug_desc_stamps(unsigned long long *out)
+{
+    unsigned int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_desc_nstamp), sizeof(n)) != hipSuccess)
+        return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_desc_stamps), sizeof(unsigned long long) * 1024 * 8) != hipSuccess)
+        return -1;
+    const unsigned int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_desc_nstamp), &zero, sizeof(zero));
+    return (int)(n < 1024 ? n : 1024);
+}
+#define STAMP(k) st[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define STAMP(k)
+#endif
+
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
                                                   const uint32_t *__restrict__ kept_xy,
                                                   const uint8_t *__restrict__ kept_resp, const int *__restrict__ nkept,
@@ -265,8 +341,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ int s_first[ORBX_MAX_LEVELS + 1];
     __shared__ float s_angle[DESC_SLOTS], s_ca[DESC_SLOTS], s_sa[DESC_SLOTS];
     __shared__ int s_m01[DESC_SLOTS], s_m10[DESC_SLOTS];  // patch moments of the block's keypoints
-    __shared__ int2 s_quad[4][DESC_KPW][16];                    // per wave and keypoint: the moments summed over each quad of lanes
-    __shared__ uint32_t s_win[4][BLP_ROWS * BLP_WORDS];  // per wave; the smaller patch reuses it
+    __shared__ int2 s_quad[4][DESC_KPW][16];              // per wave and keypoint: the moments summed over each quad of lanes
+    __shared__ uint32_t s_win[4 * BLP_SLOTS];  // a window per wave
     __shared__ uint32_t s_xy[DESC_SLOTS];                // level coordinates of the block's keypoints
     __shared__ int s_lvl[DESC_SLOTS], s_ki[DESC_SLOTS];  // their level and index into the kept arrays
     __shared__ int s_pitch[DESC_SLOTS], s_off[DESC_SLOTS];  // row pitch and slab offset of that level (blurred image)
@@ -276,6 +352,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
         return;
+#ifdef DESC_STAMPS
+    unsigned long long st[8];
+#endif
+    STAMP(0);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
         int acc = 0;
@@ -292,8 +372,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const int base = unit * DESC_SLOTS;
     if (base >= total)
         return;
-    uint32_t *win = s_win[wv];
-    const uint8_t *winb = reinterpret_cast<const uint8_t *>(win);
+    STAMP(1);
     // all keypoints of the block are located with one round of loads, so that the window fetches
     // below depend on LDS only
     if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
@@ -315,78 +394,54 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_xy[threadIdx.x] = kept_xy[(size_t)f * a.kp_per_frame + ki];
     }
     __syncthreads();
+    STAMP(2);
     // everything a window fetch needs comes from LDS: no global load sits in front of it
     const int nmine = min(DESC_KPW, total - (base + wv * DESC_KPW));  // keypoints of this wave (may be <= 0)
 
-    // ---- IC_Angle: lanes 0..30 take columns u=-15..15 of rows v = 0,2,4.., lanes 32..62 of rows 1,3,5.. ----
-    // The window of keypoint i+1 is fetched into registers while keypoint i is summed.
-    uint32_t tmp[7];
-    int ox_next = 0;
-    // The keypoint is the same for all lanes of the wave: its position and the level's pitch are made
-    // wave-uniform, so the window's start is a scalar address and a lane adds only row * pitch + 4 * word.
-    int pr[5], pc[5];  // this lane's (row, byte column) of the patch words it fetches
+    // ---- IC_Angle (src/ORBextractor.cc:85-117 of the reference) ----
+    uint32_t wu[PAT_REGS], wvv[PAT_REGS], prow[PAT_REGS], pcol[PAT_REGS];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const int idx = lane + 64 * j;
-        pr[j] = idx / PAT_WORDS, pc[j] = 4 * (idx % PAT_WORDS);
+    for (int j = 0; j < PAT_REGS; j++) {
+        const uint32_t idx = min(lane, 62) + 63 * j;  // lane 63 repeats lane 62 and weighs 0
+        const uint32_t q = __umul24(idx, 7282u) >> 16;  // idx / 9
+        const uint32_t r = q < PAT_ROWS ? q : PAT_ROWS - 1;  // words of rows past the 31st weigh 0 and reread it
+        prow[j] = r, pcol[j] = 4 * (idx - __umul24(q, PAT_WORDS));
+        wu[j] = c_patch_w.wu[j][lane], wvv[j] = c_patch_w.wv[j][lane];
     }
-    auto fetch_patch = [&](int slot) {
-        const int ls = slot - base;
+    auto fetch_patch = [&](int ls, uint32_t (&tmp)[PAT_REGS], uint32_t &ox) {
         const uint32_t xy = __builtin_amdgcn_readfirstlane(s_xy[ls]);
         const int x = xy & 0xffff, y = xy >> 16;
         const int pitch = __builtin_amdgcn_readfirstlane(s_upitch[ls]);
         const long long usrc = ((long long)__builtin_amdgcn_readfirstlane((int)(s_usrc[ls] >> 32)) << 32) |
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)s_usrc[ls]);
         const int xa = (x - 15) & ~3;
-        ox_next = (x - 15) - xa;
+        ox = (uint32_t)((x - 15) - xa);
         const uint8_t *src = pyr + usrc + (long long)(y - 15) * pitch + xa;
 #pragma unroll
-        for (int j = 0; j < 5; j++)
-            tmp[j] = lane + 64 * j < PAT_ROWS * PAT_WORDS
-                         ? *reinterpret_cast<const uint32_t *>(src + (uint32_t)(pr[j] * pitch + pc[j]))
-                         : 0u;
+        for (int j = 0; j < PAT_REGS; j++)  // rows and pitch are below 2^13
+            tmp[j] = *reinterpret_cast<const uint32_t *>(src + (__umul24(DESC_EXP_ROW(prow[j]), (uint32_t)pitch) + pcol[j]));
     };
-    // weights of the patch rows this lane sums: column u = (lane & 31) - 15, rows +-(half + 2k)
-    const int icu = min((lane & 31), 30) - 15, ichalf = lane >> 5;
-    int wu[8], wum[8], wv_[8];
-    {
-        constexpr int UM_EVEN[8] = {15, 15, 14, 14, 13, 11, 9, 6};  // half-widths of the circular patch,
-        constexpr int UM_ODD[8] = {15, 15, 14, 13, 12, 10, 8, 3};   // even and odd rows
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int vv = ichalf + 2 * k;
-            const bool in = (lane & 31) < 31 && abs(icu) <= (ichalf ? UM_ODD[k] : UM_EVEN[k]);
-            wu[k] = in ? icu : 0;
-            wum[k] = (in && vv != 0) ? icu : 0;  // row 0 is one row, not a pair
-            wv_[k] = in ? vv : 0;
-        }
-    }
+    uint32_t pt[PAT_REGS], pox = 0;
     if (nmine > 0)
-        fetch_patch(base + wv * DESC_KPW);
+        fetch_patch(wv * DESC_KPW, pt, pox);
     for (int i = 0; i < nmine; i++) {
-        const int ls = wv * DESC_KPW + i;
-        const int ox = ox_next;
+        // the four pixels from x - 15 + 4 * word on: this word and the next one (the neighbour lane's),
+        // shifted by the patch's offset in its first word; then I - 128 as signed bytes
+        const uint32_t ox = pox;
+        uint32_t px[PAT_REGS];
 #pragma unroll
-        for (int j = 0; j < 5; j++)
-            if (lane + 64 * j < PAT_ROWS * PAT_WORDS)
-                win[lane + 64 * j] = tmp[j];
-        if (i + 1 < nmine)
-            fetch_patch(base + ls + 1);
-        __builtin_amdgcn_wave_barrier();
-        int m10 = 0, m01 = 0;
-        {
-            // pixels outside the circular patch (and lanes 31, 63) enter with weight 0: no branches
-            const uint8_t *ctr = winb + 15 * (PAT_WORDS * 4) + ox + 15 + icu;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int vv = ichalf + 2 * k;
-                const int vp = ctr[vv * (PAT_WORDS * 4)], vm = ctr[-vv * (PAT_WORDS * 4)];
-                m10 = __mul24(vp, wu[k]) + m10;
-                m10 = __mul24(vm, wum[k]) + m10;
-                m01 = __mul24(vp - vm, wv_[k]) + m01;
-            }
+        for (int j = 0; j < PAT_REGS; j++) {
+            const uint32_t nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)pt[j], 0x130, 0xf, 0xf, true);  // wave_shl:1
+            px[j] = __builtin_amdgcn_alignbyte(nxt, pt[j], ox) ^ 0x80808080u;
         }
-        __builtin_amdgcn_wave_barrier();
+        if (i + 1 < nmine)
+            fetch_patch(wv * DESC_KPW + i + 1, pt, pox);
+        int m10 = 0, m01 = 0;
+#pragma unroll
+        for (int j = 0; j < PAT_REGS; j++) {
+            m10 = __builtin_amdgcn_sdot4((int)px[j], (int)wu[j], m10, false);
+            m01 = __builtin_amdgcn_sdot4((int)px[j], (int)wvv[j], m01, false);
+        }
         // Sums over the wave: here only over the four lanes of a quad (two cross-lane additions each);
         // the sixteen quad sums of every keypoint are added up after the loop, one lane per keypoint,
         // instead of a full wave-wide reduction per keypoint.
@@ -397,6 +452,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         if ((lane & 3) == 0)
             s_quad[wv][i][lane >> 2] = make_int2(m10, m01);
     }
+    STAMP(3);
     __builtin_amdgcn_wave_barrier();
     if (lane < nmine) {
         int m10 = 0, m01 = 0;
@@ -408,6 +464,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_m01[wv * DESC_KPW + lane] = m01, s_m10[wv * DESC_KPW + lane] = m10;
     }
     __syncthreads();
+    STAMP(4);
     // the angles of the block's keypoints, one thread each (inside the loop every lane of a wave would
     // step through the polynomial for one keypoint)
     if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
@@ -415,62 +472,77 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_angle[threadIdx.x] = ang;
         const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
         const float rad = __fmul_rn(ang, factorPI);
-        s_ca[threadIdx.x] = (float)cos((double)rad);
-        s_sa[threadIdx.x] = (float)sin((double)rad);
+        double sn, cs;
+#ifdef DESC_FAST_ANGLE
+        sn = __sinf(rad), cs = __cosf(rad);
+#else
+        sincos((double)rad, &sn, &cs);
+#endif
+        s_ca[threadIdx.x] = (float)cs;
+        s_sa[threadIdx.x] = (float)sn;
     }
     __syncthreads();
+    STAMP(5);
 
     // ---- steered BRIEF: lane L evaluates tests L, L+64, L+128, L+192; a ballot yields 64 descriptor bits ----
-    float px0[4], py0[4], px1[4], py1[4];
+    float4 pat[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const char4 p = *reinterpret_cast<const char4 *>(&c_pattern[(lane + 64 * j) * 4]);
-        px0[j] = (float)p.x, py0[j] = (float)p.y, px1[j] = (float)p.z, py1[j] = (float)p.w;
-    }
-    int br[7], bc[7];  // this lane's (row, byte column) of the window words it fetches
+    for (int j = 0; j < 4; j++)
+        pat[j] = *reinterpret_cast<const float4 *>(&c_pattern_f.v[(lane + 64 * j) * 4]);
+    uint32_t brow[BLP_REGS], bcol[BLP_REGS];  // this lane's (row, byte column) of the window words it fetches
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        const int idx = lane + 64 * j;
-        br[j] = idx / BLP_WORDS, bc[j] = 4 * (idx % BLP_WORDS);
+    for (int j = 0; j < BLP_REGS; j++) {
+        const uint32_t idx = lane + 64 * j;
+        const uint32_t q = __umul24(idx, 5958u) >> 16;  // idx / 11
+        const uint32_t r = q < BLP_ROWS ? q : BLP_ROWS - 1;  // slots 407 .. 447 read row 36 again
+        brow[j] = r, bcol[j] = 4 * (idx - __umul24(q, BLP_WORDS));
     }
-    auto fetch_window = [&](int slot) {
-        const int ls = slot - base;
+    auto fetch_window = [&](int ls, uint32_t (&tmp)[BLP_REGS], uint32_t &ox) {
         const uint32_t xy = __builtin_amdgcn_readfirstlane(s_xy[ls]);
         const int x = xy & 0xffff, y = xy >> 16;
         const int pitch = __builtin_amdgcn_readfirstlane(s_pitch[ls]);
         const int off = __builtin_amdgcn_readfirstlane(s_off[ls]);
         const int xa = (x - 18) & ~3;
-        ox_next = (x - 18) - xa;
+        ox = (uint32_t)((x - 18) - xa);
         const uint8_t *src = blur + (size_t)f * a.slab + off + (long long)(y - 18) * pitch + xa;
 #pragma unroll
-        for (int j = 0; j < 7; j++)
-            tmp[j] = lane + 64 * j < BLP_ROWS * BLP_WORDS
-                         ? *reinterpret_cast<const uint32_t *>(src + (uint32_t)(br[j] * pitch + bc[j]))
-                         : 0u;
+        for (int j = 0; j < BLP_REGS; j++)
+            tmp[j] = *reinterpret_cast<const uint32_t *>(src + (__umul24(DESC_EXP_ROW(brow[j]), (uint32_t)pitch) + bcol[j]));
     };
+    uint32_t *win = s_win + wv * BLP_SLOTS;
+    // Rounding to the nearest integer, ties to even, by adding 1.5 * 2^23: the sum's bit pattern is
+    // 0x4b400000 + n.  A 24-bit multiply sees 0x400000 + n of it, so row * 44 + column comes out as
+    // 44 * n_row + n_col + RND_BIAS in one multiply-add of the two bit patterns.
+    const float RND = 12582912.f;
+    const uint32_t RND_BIAS = 0x400000u * (BLP_WORDS * 4) + 0x4b400000u;
+    const uint32_t ctr0 = (uint32_t)(wv * BLP_SLOTS * 4 + 18 * (BLP_WORDS * 4) + 18) - RND_BIAS;
+    const uint8_t *winb = reinterpret_cast<const uint8_t *>(s_win);
+    uint32_t wt[BLP_REGS], wox = 0;
     if (nmine > 0)
-        fetch_window(base + wv * DESC_KPW);
+        fetch_window(wv * DESC_KPW, wt, wox);
     for (int i = 0; i < nmine; i++) {
         const int ls = wv * DESC_KPW + i, slot = base + ls;
-        const int ox = ox_next;
         __builtin_amdgcn_wave_barrier();  // the previous keypoint's samples are read before this overwrite
+        const uint32_t ctr = ctr0 + wox;  // the window's offset in its first word
 #pragma unroll
-        for (int j = 0; j < 7; j++)
-            if (lane + 64 * j < BLP_ROWS * BLP_WORDS)
-                win[lane + 64 * j] = tmp[j];
+        for (int j = 0; j < BLP_REGS; j++)
+            win[lane + 64 * j] = wt[j];
         if (i + 1 < nmine)
-            fetch_window(slot + 1);
+            fetch_window(ls + 1, wt, wox);
         __builtin_amdgcn_wave_barrier();
-        const float ca = s_ca[ls], sa = s_sa[ls];
-        const uint8_t *ctr = winb + 18 * (BLP_WORDS * 4) + ox + 18;
+        const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(s_ca[ls])));
+        const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(s_sa[ls])));
         unsigned long long bits[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(px0[j], sa), __fmul_rn(py0[j], ca)));
-            const int q0 = __float2int_rn(__fsub_rn(__fmul_rn(px0[j], ca), __fmul_rn(py0[j], sa)));
-            const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(px1[j], sa), __fmul_rn(py1[j], ca)));
-            const int q1 = __float2int_rn(__fsub_rn(__fmul_rn(px1[j], ca), __fmul_rn(py1[j], sa)));
-            const int t0 = ctr[r0 * (BLP_WORDS * 4) + q0], t1 = ctr[r1 * (BLP_WORDS * 4) + q1];
+            // rows x * sin + y * cos, columns x * cos - y * sin, each operation rounded (src/ORBextractor.cc:124-135)
+            const float r0 = __fadd_rn(__fadd_rn(__fmul_rn(pat[j].x, sa), __fmul_rn(pat[j].y, ca)), RND);
+            const float q0 = __fadd_rn(__fsub_rn(__fmul_rn(pat[j].x, ca), __fmul_rn(pat[j].y, sa)), RND);
+            const float r1 = __fadd_rn(__fadd_rn(__fmul_rn(pat[j].z, sa), __fmul_rn(pat[j].w, ca)), RND);
+            const float q1 = __fadd_rn(__fsub_rn(__fmul_rn(pat[j].z, ca), __fmul_rn(pat[j].w, sa)), RND);
+            const uint32_t k0 = (uint32_t)__mul24(__float_as_int(r0), BLP_WORDS * 4) + __float_as_uint(q0) + ctr;
+            const uint32_t k1 = (uint32_t)__mul24(__float_as_int(r1), BLP_WORDS * 4) + __float_as_uint(q1) + ctr;
+            const int t0 = winb[k0], t1 = winb[k1];
             bits[j] = __ballot(t0 < t1);
         }
         const size_t o = (size_t)f * a.out_cap + slot;
@@ -478,6 +550,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             *reinterpret_cast<unsigned long long *>(out_desc + o * 32 + lane * 8) =
                 lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
     }
+    STAMP(6);
     // the keypoint records, one thread each
     if (threadIdx.x < DESC_SLOTS && base + (int)threadIdx.x < total) {
         const int ls = threadIdx.x;
@@ -495,6 +568,15 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         kp.class_id = -1;
         out_kp[(size_t)f * a.out_cap + base + ls] = kp;
     }
+#ifdef DESC_STAMPS
+    STAMP(7);
+    if (threadIdx.x == 0 && (unit % 5) == 0) {
+        const unsigned int k = atomicAdd(&g_desc_nstamp, 1u);
+        if (k < 1024)
+            for (int i = 0; i < 8; i++)
+                g_desc_stamps[k][i] = st[i];
+    }
+#endif
 }
 
 hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)

@@ -37,99 +37,122 @@ hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, c
 // Horizontal pass in int32 (S[sx]*a0 + S[sx+1]*a1), vertical pass
 // ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.  Source positions and coefficients come from
 // tables built on the host for the current image size (they depend on the column or row only).
-#define RS_ROWS 2  // destination rows per thread
+#ifndef RS_ROWS
+#define RS_ROWS 8  // destination rows per wave
+#endif
 
 typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
 
-// Each thread produces 4 adjacent pixels of RS_ROWS destination rows.  When the source bytes of the
-// four pixels lie within 8 bytes of the first one (any scale factor up to 2), each source row costs
-// one 12-byte load from the aligned word below the first pixel, two byte alignments that bring the
-// first pixel to byte 0, and per pixel one byte permute (the two neighbours as a 2 x u16 vector) and
-// one 2 x u16 dot product with the packed coefficient pair.  Threads whose 12 bytes would end
-// behind `src_bytes` (the readable bytes of a frame) take the byte-wise path.
+// A wave produces RS_ROWS destination rows of 256 pixels, each lane 4 adjacent pixels of every row.  The
+// rows of a wave are uniform, so the wave walks down the source rows its destination rows read and
+// keeps the horizontal pass of the row before: at a scale factor of 1.2 the upper source row of a
+// destination row is the lower one of the row before in four cases of five, so a source row is read
+// and filtered once, not twice.  The row bookkeeping is scalar.
+// When the source bytes of a lane's four pixels lie within 8 bytes of the first one (any scale
+// factor up to 2), a source row costs one 12-byte load from the aligned word below the first pixel,
+// two byte alignments that bring the first pixel to byte 0, and per pixel one byte permute (the two
+// neighbours as a 2 x u16 vector) and one 2 x u16 dot product with the packed coefficient pair.  Lanes
+// whose 12 bytes would end behind `src_bytes` (the readable bytes of a frame) take the byte-wise path.
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_lvl, long long src_fstride,
                                                 uint32_t src_bytes, uint8_t *__restrict__ pyr_out, int slab, int spitch,
                                                 int doff, int dpitch, int dw, int dh,
                                                 const OrbxXCoef *__restrict__ xt, const OrbxYCoef *__restrict__ yt)
 {
     const int f = blockIdx.z;
-    const int dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS;
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS);
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     if (dy0 >= dh || dx0 >= dw)
         return;
-    // the tables are padded to a multiple of 4 columns / RS_ROWS rows with copies of the last entry
+    const int dy1 = min(dy0 + RS_ROWS, dh);
+    // the column table is padded to a multiple of 4 columns with copies of the last entry
     const uint4 t0 = *reinterpret_cast<const uint4 *>(xt + dx0), t1 = *reinterpret_cast<const uint4 *>(xt + dx0 + 2);
     const int sx[4] = {(int)t0.x, (int)t0.z, (int)t1.x, (int)t1.z};
     const uint32_t coef[4] = {t0.y, t0.w, t1.y, t1.w};  // a0 | a1 << 16
-    uint4 cy[RS_ROWS];  // sy0, sy1, b0, b1
-#pragma unroll
-    for (int r = 0; r < RS_ROWS; r++)
-        cy[r] = *reinterpret_cast<const uint4 *>(yt + dy0 + r);
     const uint8_t *sbase = src_lvl + (size_t)f * src_fstride;
     uint8_t *dbase = pyr_out + (size_t)f * slab + doff;
     const uint32_t wb = (uint32_t)sx[0] & ~3u;  // aligned byte offset of the first word
     const uint32_t s0 = (uint32_t)sx[0] & 3u;
-    const uint32_t last_row = max(max(cy[0].x, cy[0].y), max(cy[1].x, cy[1].y));
+    const uint32_t last_row = (uint32_t)yt[dy1 - 1].sy1;  // source rows ascend with the destination row
     const bool narrow = sx[3] + 1 - sx[0] <= 7 && __umul24(last_row, (uint32_t)spitch) + wb + 12u <= src_bytes;
-    uint32_t h[RS_ROWS][2][4];
-    if (narrow) {
-        uint32_t sel[4];
+    uint32_t sel[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        sel[i] = (uint32_t)(sx[i] - sx[0]) * 0x00010001u + 0x0c010c00u;  // bytes d, 0, d+1, 0
+
+    // horizontal pass of one source row, S[sx] * a0 + S[sx + 1] * a1 for the lane's four pixels, from the
+    // three words `w` loaded ahead (narrow lanes) or from single bytes
+    const uint32_t wb_safe = narrow ? wb : 0u;  // other lanes load the words at the row's start and ignore them
+    auto load_row = [&](int srow, uint32_t (&w)[3]) {
+        const uint32_t *row =
+            reinterpret_cast<const uint32_t *>(sbase + __umul24((uint32_t)srow, (uint32_t)spitch) + wb_safe);
+        w[0] = row[0], w[1] = row[1], w[2] = row[2];  // rows and pitch are below 2^13
+    };
+    auto hpass = [&](int srow, const uint32_t (&w)[3], uint32_t (&o)[4]) {
+        if (narrow) {
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w[1], w[0], s0);  // source bytes sx0 .. sx0+3
+            const uint32_t hi = __builtin_amdgcn_alignbyte(w[2], w[1], s0);  // source bytes sx0+4 .. sx0+7
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t pq = __builtin_amdgcn_perm(hi, lo, sel[i]);
+                o[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, pq), __builtin_bit_cast(rs_us2, coef[i]), 0u,
+                                              false);
+            }
+        } else {
+            const uint8_t *row = sbase + __umul24((uint32_t)srow, (uint32_t)spitch);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // a1 == 0 marks columns whose right neighbour must not be read
+                const uint32_t a0 = coef[i] & 0xffffu, a1 = coef[i] >> 16;
+                const int s1 = a1 ? sx[i] + 1 : sx[i];
+                o[i] = row[sx[i]] * a0 + row[s1] * a1;
+            }
+        }
+    };
+
+    // Source rows first_row .. last_row in turn, the next one loading while this one is filtered.  A
+    // destination row reads source rows (j - 1, j), or (j, j) where the table clamps at the last row, and
+    // is written when row j has been filtered.
+    const int first_row = yt[dy0].sy0;
+    uint32_t ahead[3] = {0, 0, 0}, prev[4] = {0, 0, 0, 0};
+    load_row(first_row, ahead);
+    int dy = dy0;
+    OrbxYCoef c = yt[dy];
+    for (int j = first_row; j <= (int)last_row; j++) {
+        const uint32_t raw[3] = {ahead[0], ahead[1], ahead[2]};
+        if (j < (int)last_row)
+            load_row(j + 1, ahead);
+        uint32_t cur[4];
+        hpass(j, raw, cur);
+        while (dy < dy1 && c.sy1 == j) {
+            // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 for four pixels: the upper halves
+            // of the eight products are gathered two pixels to a register and added, rounded and shifted as
+            // packed 16-bit values (both products stay below 2^27, so 24-bit multiplies are exact)
+            if (c.sy0 == j) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    prev[i] = cur[i];
+            }
+            uint32_t p0[4], p1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                p0[i] = __umul24((uint32_t)c.b0, prev[i] >> 4);
+                p1[i] = __umul24((uint32_t)c.b1, cur[i] >> 4);
+            }
+            typedef unsigned short rs_pk __attribute__((ext_vector_type(2)));
+            auto pair = [&](int i) -> uint32_t {
+                const uint32_t t = __builtin_amdgcn_perm(p0[i + 1], p0[i], 0x07060302u);  // hi16(p0[i]) | hi16(p0[i+1]) << 16
+                const uint32_t u = __builtin_amdgcn_perm(p1[i + 1], p1[i], 0x07060302u);
+                const rs_pk sum = __builtin_bit_cast(rs_pk, t) + __builtin_bit_cast(rs_pk, u) + (rs_pk){2, 2};
+                return __builtin_bit_cast(uint32_t, (rs_pk)(sum >> (rs_pk){2, 2}));
+            };
+            const uint32_t out = __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u);  // the four low bytes
+            *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy, dpitch) + dx0)) = out;
+            if (++dy < dy1)
+                c = yt[dy];
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            sel[i] = (uint32_t)(sx[i] - sx[0]) * 0x00010001u + 0x0c010c00u;  // bytes d, 0, d+1, 0
-#pragma unroll
-        for (int r = 0; r < RS_ROWS; r++)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint32_t off = __umul24(k ? cy[r].y : cy[r].x, (uint32_t)spitch) + wb;  // rows and pitch are below 2^13
-                const uint32_t *row = reinterpret_cast<const uint32_t *>(sbase + off);
-                const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
-                const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, s0);  // source bytes sx0 .. sx0+3
-                const uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, s0);  // source bytes sx0+4 .. sx0+7
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t pq = __builtin_amdgcn_perm(hi, lo, sel[i]);
-                    h[r][k][i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, pq),
-                                                        __builtin_bit_cast(rs_us2, coef[i]), 0u, false);
-                }
-            }
-    } else {
-#pragma unroll
-        for (int r = 0; r < RS_ROWS; r++)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint8_t *row = sbase + __umul24(k ? cy[r].y : cy[r].x, (uint32_t)spitch);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    // a1 == 0 marks columns whose right neighbour must not be read
-                    const uint32_t a0 = coef[i] & 0xffffu, a1 = coef[i] >> 16;
-                    const int s1 = a1 ? sx[i] + 1 : sx[i];
-                    h[r][k][i] = row[sx[i]] * a0 + row[s1] * a1;
-                }
-            }
-    }
-#pragma unroll
-    for (int r = 0; r < RS_ROWS; r++) {
-        if (dy0 + r >= dh)
-            break;
-        // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 for four pixels: the upper halves of
-        // the eight products are gathered two pixels to a register and added, rounded and shifted as packed
-        // 16-bit values (both products stay below 2^27, so 24-bit multiplies are exact)
-        uint32_t p0[4], p1[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            p0[i] = __umul24(cy[r].z, h[r][0][i] >> 4);
-            p1[i] = __umul24(cy[r].w, h[r][1][i] >> 4);
-        }
-        typedef unsigned short rs_pk __attribute__((ext_vector_type(2)));
-        auto pair = [&](int i) -> uint32_t {
-            const uint32_t t = __builtin_amdgcn_perm(p0[i + 1], p0[i], 0x07060302u);  // hi16(p0[i]) | hi16(p0[i+1]) << 16
-            const uint32_t u = __builtin_amdgcn_perm(p1[i + 1], p1[i], 0x07060302u);
-            const rs_pk sum = __builtin_bit_cast(rs_pk, t) + __builtin_bit_cast(rs_pk, u) + (rs_pk){2, 2};
-            return __builtin_bit_cast(uint32_t, (rs_pk)(sum >> (rs_pk){2, 2}));
-        };
-        const uint32_t out = __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u);  // the four low bytes
-        *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy0 + r, dpitch) + dx0)) = out;
+            prev[i] = cur[i];
     }
 }
 
