@@ -214,10 +214,10 @@ constexpr PatternF make_pattern_f()
 __constant__ __attribute__((aligned(16))) PatternF c_pattern_f = make_pattern_f();
 
 // Weights of the orientation patch, one signed byte per pixel, for the words a wave holds in registers.
-// Lanes 0 .. 62 of register j hold word i = lane + 63 * j of the patch rows (9 words each, row i / 9,
-// v = row - 15); once shifted to start at x - 15 the word's bytes are u = 4 * (i % 9) + b - 15.
-// wu holds u, wv holds v, both 0 outside the circular patch, in a 32nd row and in lane 63.
-#define PAT_REGS 5
+// Lanes 0 .. 59 of register j hold word i = lane + 60 * j of the patch rows (12 words each, row i / 12,
+// v = row - 15); once shifted to start at x - 15 the word's bytes are u = 4 * (i % 12) + b - 15.
+// wu holds u, wv holds v, both 0 outside the circular patch, in rows past the 31st and in lanes 60 .. 63.
+#define PAT_REGS 7
 struct PatchWeights {
     uint32_t wu[PAT_REGS][64], wv[PAT_REGS][64];
 };
@@ -226,10 +226,10 @@ constexpr PatchWeights make_patch_weights()
     constexpr int UMAX[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
     PatchWeights t{};
     for (int j = 0; j < PAT_REGS; j++)
-        for (int l = 0; l < 63; l++) {
-            const int i = l + 63 * j, v = i / 9 - 15;
+        for (int l = 0; l < 60; l++) {
+            const int i = l + 60 * j, v = i / 12 - 15;
             for (int b = 0; b < 4; b++) {
-                const int u = 4 * (i % 9) + b - 15;
+                const int u = 4 * (i % 12) + b - 15;
                 const int au = u < 0 ? -u : u, av = v < 0 ? -v : v;
                 if (av <= 15 && au <= UMAX[av]) {
                     t.wu[j][l] |= (uint32_t)(u & 0xff) << (8 * b);
@@ -285,24 +285,25 @@ struct DescArgs {
 #endif
 #define DESC_SLOTS (4 * DESC_KPW)  // keypoint slots per workgroup
 #define PAT_ROWS 31    // orientation patch: rows y-15 .. y+15
-#define PAT_WORDS 9    // 36 fetched bytes per row from the aligned word at or below x-15
+#define PAT_WORDS 12   // 48 fetched bytes per row from the aligned word at or below x-15 (36 are needed)
 #define BLP_ROWS 37    // descriptor window on the blurred level: rows y-18 .. y+18
-#define BLP_WORDS 11   // 44 staged bytes per row from the aligned word at or below x-18
+#define BLP_WORDS 12   // 48 staged bytes per row from the aligned word at or below x-18 (44 are needed)
 #define BLP_REGS 7     // window words per lane
 #define BLP_SLOTS (64 * BLP_REGS)  // words of a wave's window buffer
 
 // One workgroup per DESC_SLOTS consecutive output slots of a frame, DESC_KPW keypoints per wave.  A
 // keypoint is the same for all lanes of its wave, so the start of its windows is a scalar address and
-// a lane adds only row * pitch + 4 * word.  The windows are fetched as aligned words, 9 or 11 to a row
-// from the word at or below x - 15 or x - 18: the address unit takes a cycle per 64-byte line an
-// instruction touches, but four times that for words at odd byte addresses, and it is the unit a
-// wider or unaligned fetch keeps busy longest.
-// Orientation: the lane keeps its words of the 31 x 36 patch in registers, shifts each to start at
+// a lane adds only row * pitch + 4 * word.  The windows are fetched as aligned words, 12 to a row from the
+// word at or below x - 15 or x - 18 (9 or 11 would do): the address unit works on the four lanes of a
+// quad together when their words are contiguous, and one by one when a quad straddles two rows, so rows
+// of 9 or 11 words cost 24-28 clocks per load instruction, rows of 12 a third of that; words at odd byte
+// addresses or 16-byte loads cost four times as much again (tools/ubench_ta.hip).
+// Orientation: the lane keeps its words of the 31 x 48 patch in registers, shifts each to start at
 // x - 15 with the next word from its neighbour lane, and takes two signed 4 x 8-bit dot products
 // with constant weights, u and v of the circular patch (0 outside): the sums of u * (I - 128) and
 // v * (I - 128) are m10 and m01, because u and v sum to 0 over the patch.
 // In between, one thread per keypoint evaluates cos/sin in double precision (once per keypoint instead
-// of once per lane).  Descriptor: the wave copies the 37 x 44 window into LDS and each lane samples four
+// of once per lane).  Descriptor: the wave copies the 37 x 48 window into LDS and each lane samples four
 // tests.  The loads of keypoint i+1 are in flight while keypoint i is computed.
 // The fetched rows may run a few bytes past the image width: that stays inside the level slabs,
 // which are allocated with slack behind the last level.
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     uint32_t wu[PAT_REGS], wvv[PAT_REGS], prow[PAT_REGS], pcol[PAT_REGS];
 #pragma unroll
     for (int j = 0; j < PAT_REGS; j++) {
-        const uint32_t idx = min(lane, 62) + 63 * j;  // lane 63 repeats lane 62 and weighs 0
-        const uint32_t q = __umul24(idx, 7282u) >> 16;  // idx / 9
+        const uint32_t idx = min(lane, 59) + 60 * j;  // lanes 60 .. 63 repeat lane 59 and weigh 0
+        const uint32_t q = __umul24(idx, 5462u) >> 16;  // idx / 12
         const uint32_t r = q < PAT_ROWS ? q : PAT_ROWS - 1;  // words of rows past the 31st weigh 0 and reread it
         prow[j] = r, pcol[j] = 4 * (idx - __umul24(q, PAT_WORDS));
         wu[j] = c_patch_w.wu[j][lane], wvv[j] = c_patch_w.wv[j][lane];
@@ -493,8 +494,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #pragma unroll
     for (int j = 0; j < BLP_REGS; j++) {
         const uint32_t idx = lane + 64 * j;
-        const uint32_t q = __umul24(idx, 5958u) >> 16;  // idx / 11
-        const uint32_t r = q < BLP_ROWS ? q : BLP_ROWS - 1;  // slots 407 .. 447 read row 36 again
+        const uint32_t q = __umul24(idx, 5462u) >> 16;  // idx / 12
+        const uint32_t r = q < BLP_ROWS ? q : BLP_ROWS - 1;  // slots 444 .. 447 read row 36 again
         brow[j] = r, bcol[j] = 4 * (idx - __umul24(q, BLP_WORDS));
     }
     auto fetch_window = [&](int ls, uint32_t (&tmp)[BLP_REGS], uint32_t &ox) {

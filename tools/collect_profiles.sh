@@ -18,10 +18,12 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OU
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $EXCL > "$OUT/pmc_fetch.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $EXCL > "$OUT/pmc_write.log" 2>&1 || exit 1
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$OUT/pmc_sq" -- python3 $EXCL > "$OUT/pmc_sq.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_l1" -- python3 $EXCL > "$OUT/pmc_l1.log" 2>&1 || exit 1
 timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/cal_fetch" -- $REPO/tools/ubench_fetch > "$OUT/cal_fetch.log" 2>&1 || exit 1
 timeout -s KILL 60 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/cal_write" -- $REPO/tools/ubench_fetch > "$OUT/cal_write.log" 2>&1 || exit 1
 cd $REPO
 timeout -k 10 60 tools/ubench_valu > "$OUT/ubench_valu.txt" 2>/dev/null || exit 1
+timeout -k 10 60 tools/ubench_ta > "$OUT/ubench_ta.txt" 2>/dev/null || exit 1
 timeout -k 10 100 tools/bin/exp_fast 256 20 > "$OUT/exp_fast.txt" 2>/dev/null || exit 1
 timeout -k 10 60 tools/ubench_mfma_i8 > "$OUT/ubench_mfma_i8.txt" 2>/dev/null || exit 1
 timeout -k 10 60 tools/probe_mfma_f4 > "$OUT/probe_mfma_f4.txt" 2>/dev/null || exit 1

@@ -61,6 +61,21 @@ def main():
         kernels[k] = {"hbm_bytes_per_frame": hbm / frames, "fetch_kib_per_launch": f, "write_kib_per_launch": w,
                       "valu_wave_instr_per_frame": valu / frames, "salu_wave_instr_per_frame": salu / frames,
                       "lds_wave_instr_per_frame": lds / frames}
+    l1dir = os.path.join(src, "pmc_l1")
+    if os.path.isdir(l1dir):
+        l1 = load(l1dir)
+        lines.append("")
+        lines.append("vector memory path per launch (TA_TA_BUSY summed over the 256 compute units, GRBM_GUI_ACTIVE over the 8 XCDs):")
+        lines.append("%-11s %14s %16s %16s %16s %10s" % (
+            "kernel", "TA busy cyc", "L1 accesses", "L1->L2 reads", "pending stall", "TA busy"))
+        for k in ("k_resize", "k_fast", "k_gather", "k_octree", "k_blur", "k_describe"):
+            c = {n: mean(v) for n, v in l1[k].items()}
+            active = c["GRBM_GUI_ACTIVE"] / 8.0
+            lines.append("%-11s %14.0f %16.0f %16.0f %16.0f %9.0f%%" % (
+                k, c["TA_TA_BUSY_sum"], c["TCP_TOTAL_CACHE_ACCESSES_sum"], c["TCP_TCC_READ_REQ_sum"],
+                c["TCP_PENDING_STALL_CYCLES_sum"], 100.0 * c["TA_TA_BUSY_sum"] / 256.0 / active))
+            kernels[k]["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / 256.0 / active
+            kernels[k]["l1_to_l2_read_requests_per_frame"] = c["TCP_TCC_READ_REQ_sum"] / frames
     out = {"workload": bench["config"]["workload"], "frames_per_launch_measured": frames,
            "source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* passes of "
                      "'bench.py --exclusive', HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB" % dst,

@@ -57,6 +57,9 @@ int main()
         {16, 4, 1, "16B x 4 lanes/row +1"},                  {16, 2, 0, "16B x 2 lanes/row aligned (32 B rows)"},
         {16, 2, 1, "16B x 2 lanes/row +1"},                  {16, 3, 0, "16B x 3 lanes/row aligned (48 B rows)"},
         {16, 3, 2, "16B x 3 lanes/row +2"},                  {16, 1, 0, "16B x 1 lane/row"},
+        {4, 9, 0, "4B x 9 lanes/row (36 B rows) from byte 0"},  {4, 9, 44, "4B x 9 lanes/row from byte 44"},
+        {4, 11, 0, "4B x 11 lanes/row (44 B rows) from byte 0"}, {4, 11, 36, "4B x 11 lanes/row from byte 36"},
+        {16, 8, 0, "16B x 8 lanes/row aligned (128 B rows)"},
     };
     for (const Shape &s : shapes) {
         for (int rep = 0; rep < 2; rep++) {
