@@ -14,7 +14,7 @@
 
 using ORB_SLAM2::ORBextractor;
 
-// the two bodies INTEGRATION.md gives a maintainer, in a Frame / ORBmatcher of the reference's shape
+// the two bodies the integration guide gives a maintainer, in a Frame / ORBmatcher of the reference's shape
 namespace ORB_SLAM2 {
 class ORBmatcher {
 public:

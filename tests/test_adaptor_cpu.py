@@ -1,8 +1,8 @@
 """The cv:: adaptor (orbslam2_amd/cpp/ORBextractor.{h,cc}) is the one product file that needs OpenCV, which
 this image lacks.  These tests type-check and link it against the test-only cv:: stand-in under
 tests/cpp/cv_stub (declarations of Mat / KeyPoint / InputArray / OutputArray, nothing more), with the language
-level of the reference's own build (-std=c++11, CMakeLists.txt:10-18), and check that the code INTEGRATION.md
-shows is the code that is compiled."""
+level of the reference's own build (-std=c++11, CMakeLists.txt:10-18), and check that the code the integration
+guide shows is the code that is compiled."""
 import os
 import re
 import subprocess
@@ -34,11 +34,14 @@ def test_frame_style_caller_and_integration_snippets_compile_and_link(tmp_path):
          "-o", str(tmp_path / "test_adaptor")])
 
 
-def test_integration_md_shows_the_compiled_snippets():
+GUIDE = "INTEGRATION.md"  # the integration guide at the repository root
+
+
+def test_integration_guide_shows_the_compiled_snippets():
     norm = lambda t: re.sub(r"\s+", " ", t).strip()
     compiled = norm(open(os.path.join(ROOT, "tests", "cpp", "integration_snippets.inc")).read())
-    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    md = open(os.path.join(ROOT, GUIDE)).read()
     blocks = re.findall(r"<!-- compiled: tests/cpp/integration_snippets.inc -->\s*```cpp\n(.*?)```", md, re.S)
-    assert len(blocks) >= 2, "INTEGRATION.md must mark the DescriptorDistance and ComputeStereoMatches bodies"
+    assert len(blocks) >= 2, GUIDE + " must mark the DescriptorDistance and ComputeStereoMatches bodies"
     for b in blocks:
-        assert norm(b) in compiled, "INTEGRATION.md snippet differs from the compiled one:\n" + b
+        assert norm(b) in compiled, GUIDE + " snippet differs from the compiled one:\n" + b

@@ -78,7 +78,7 @@ def test_cpp_host_layer_matches_python_binding():
 def test_cv_adaptor_driven_like_frame():
     """ORB_SLAM2::ORBextractor (orbslam2_amd/cpp/ORBextractor.{h,cc}) called the way src/Frame.cc:62-118, 256-262
     calls the class it replaces: two extractors in two threads, cv::KeyPoint / cv::Mat outputs, the lazily
-    fetched mvImagePyramid, DescriptorDistance and ComputeStereoMatches as INTEGRATION.md writes them.  The
+    fetched mvImagePyramid, DescriptorDistance and ComputeStereoMatches as the integration guide writes them.  The
     program checks every result against the same call through the C ABI."""
     exe = os.path.join(ROOT, "tests", "cpp", "test_adaptor")
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
