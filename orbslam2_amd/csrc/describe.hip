@@ -42,10 +42,12 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 
 // Separable fixed-point filter: horizontal sums fit 16 bits (kernel sum <= 257), the vertical pass
 // rounds with +32768 and shifts by 16; variant 1 (kernel sum 257) saturates to 255.
-// Horizontal pass: a work item is 4 pixels of two rows; each sum is two 4-byte dot products on byte
-// windows cut from three staged words; the two rows' sums of a column share one LDS word.
+// Horizontal pass: a work item is 4 pixels of two rows; each sum is two or three 4-byte dot products of the
+// three staged words around the pixels with the taps laid out at the pixel's offset; the two rows' sums of a
+// column share one LDS word.
 // Vertical pass: a thread takes 4 pixels of four rows; the 7 taps of a pixel are four 2 x u16 dot
 // products on those row-pair words (the row's parity decides where the zero tap sits).
+template <int VARIANT>  // 0: taps 18 34 48 56 (sum 256), 1: 18 34 49 55 (sum 257)
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, BlurArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t img[BL_SH * BL_SWORDS];
@@ -62,9 +64,12 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int spitch = lvl == 0 ? a.l0.pitch : pitch;
     const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
     uint8_t *dst = blur + (size_t)f * a.slab + a.off[lvl];
-    const uint32_t k0 = 18, k1 = 34, k2 = a.variant ? 49 : 48, k3 = a.variant ? 55 : 56;
-    const uint32_t kA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);  // taps 0..3
-    const uint32_t kB = k2 | (k1 << 8) | (k0 << 16);               // taps 4..6
+    const uint32_t k0 = 18, k1 = 34, k2 = VARIANT ? 49 : 48, k3 = VARIANT ? 55 : 56;
+    // the seven taps k0 k1 k2 k3 k2 k1 k0 laid over bytes o+1 .. o+7 of three words, for o = 0 .. 3
+    const uint32_t t0a = (k0 << 8) | (k1 << 16) | (k2 << 24), t0b = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
+    const uint32_t t1a = (k0 << 16) | (k1 << 24), t1b = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), t1c = k0;
+    const uint32_t t2a = k0 << 24, t2b = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), t2c = k1 | (k0 << 8);
+    const uint32_t t3b = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), t3c = k2 | (k1 << 8) | (k0 << 16);
 
     // interior: every needed pixel (3 around the tile) exists and whole 16-byte pieces can be read
     const bool interior = tx0 >= BL_LEFT && tx0 + BL_W + 3 <= w && tx0 + BL_W + 16 <= spitch && ty0 >= 3 &&
@@ -124,16 +129,17 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             uint32_t hv[2][4];
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
-                // staged words cg+3 .. cg+5 hold columns x-4 .. x+7 of the group's first pixel x
+                // staged words cg+3 .. cg+5 hold columns x-4 .. x+7 of the group's first pixel x; pixel x+o
+                // has its taps at bytes o+1 .. o+7 of the three words: the taps, not the bytes, are shifted
+                // (constant words), so a pixel is two or three 4-byte dot products and nothing else
                 const uint32_t *wp = &img[(2 * p + rr) * BL_SWORDS + cg + 3];
                 const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2];
-#pragma unroll
-                for (int o = 0; o < 4; o++) {
-                    // pixel x+o: taps at bytes o+1 .. o+7 of the three words
-                    const uint32_t lo = o == 3 ? w1 : __builtin_amdgcn_alignbyte(w1, w0, o + 1);  // bytes o+1..o+4
-                    const uint32_t hi = o == 3 ? w2 : __builtin_amdgcn_alignbyte(w2, w1, o + 1);  // bytes o+5..o+8
-                    hv[rr][o] = __builtin_amdgcn_udot4(hi, kB, __builtin_amdgcn_udot4(lo, kA, 0u, false), false);
-                }
+                hv[rr][0] = __builtin_amdgcn_udot4(w1, t0b, __builtin_amdgcn_udot4(w0, t0a, 0u, false), false);
+                hv[rr][1] = __builtin_amdgcn_udot4(
+                    w2, t1c, __builtin_amdgcn_udot4(w1, t1b, __builtin_amdgcn_udot4(w0, t1a, 0u, false), false), false);
+                hv[rr][2] = __builtin_amdgcn_udot4(
+                    w2, t2c, __builtin_amdgcn_udot4(w1, t2b, __builtin_amdgcn_udot4(w0, t2a, 0u, false), false), false);
+                hv[rr][3] = __builtin_amdgcn_udot4(w2, t3c, __builtin_amdgcn_udot4(w1, t3b, 0u, false), false);
             }
             uint4 pk;
             pk.x = hv[0][0] | (hv[1][0] << 16);
@@ -168,10 +174,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             acc[1] = dot2_u16(q[p0 + 3].y, c67, dot2_u16(q[p0 + 2].y, c45, dot2_u16(q[p0 + 1].y, c23, dot2_u16(q[p0].y, c01, 32768u))));
             acc[2] = dot2_u16(q[p0 + 3].z, c67, dot2_u16(q[p0 + 2].z, c45, dot2_u16(q[p0 + 1].z, c23, dot2_u16(q[p0].z, c01, 32768u))));
             acc[3] = dot2_u16(q[p0 + 3].w, c67, dot2_u16(q[p0 + 2].w, c45, dot2_u16(q[p0 + 1].w, c23, dot2_u16(q[p0].w, c01, 32768u))));
-            // byte 2 of each sum is the result; a sum of 2^24 (variant 1 only) saturates to 255
+            // byte 2 of each sum is the result; a sum of 2^24 (variant 1 only: its taps add up to 257)
+            // saturates to 255
+            if (VARIANT) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                acc[i] = min(acc[i], 0x00ffffffu);
+                for (int i = 0; i < 4; i++)
+                    acc[i] = min(acc[i], 0x00ffffffu);
+            }
             const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);  // bytes: acc0.b2, acc1.b2
             const uint32_t hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);  // upper half: acc2.b2, acc3.b2
             *reinterpret_cast<uint32_t *>(dst + (uint32_t)(__umul24(y, pitch) + x)) = lo | hi;
@@ -190,7 +199,10 @@ hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
         a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
     }
     a.tile_base[g.nlevels] = g.tiles_per_frame;
-    k_blur<<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, a);
+    if (g.blur_variant)
+        k_blur<1><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, a);
+    else
+        k_blur<0><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, a);
     return hipGetLastError();
 }
 
