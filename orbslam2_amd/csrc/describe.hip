@@ -370,6 +370,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #endif
     STAMP(0);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the constant weight words of the orientation patch: loaded first, so that they have arrived long before the
+    // keypoint loop (see the wait in front of it)
+    uint32_t wu[PAT_REGS], wvv[PAT_REGS];
+#pragma unroll
+    for (int j = 0; j < PAT_REGS; j++)
+        wu[j] = c_patch_w.wu[j][lane], wvv[j] = c_patch_w.wv[j][lane];
     if (threadIdx.x == 0) {
         int acc = 0;
         for (int l = 0; l < a.nlevels; l++) {
@@ -412,14 +418,13 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const int nmine = min(DESC_KPW, total - (base + wv * DESC_KPW));  // keypoints of this wave (may be <= 0)
 
     // ---- IC_Angle (src/ORBextractor.cc:85-117 of the reference) ----
-    uint32_t wu[PAT_REGS], wvv[PAT_REGS], prow[PAT_REGS], pcol[PAT_REGS];
+    uint32_t prow[PAT_REGS], pcol[PAT_REGS];
 #pragma unroll
     for (int j = 0; j < PAT_REGS; j++) {
         const uint32_t idx = min(lane, 59) + 60 * j;  // lanes 60 .. 63 repeat lane 59 and weigh 0
         const uint32_t q = __umul24(idx, 5462u) >> 16;  // idx / 12
         const uint32_t r = q < PAT_ROWS ? q : PAT_ROWS - 1;  // words of rows past the 31st weigh 0 and reread it
         prow[j] = r, pcol[j] = 4 * (idx - __umul24(q, PAT_WORDS));
-        wu[j] = c_patch_w.wu[j][lane], wvv[j] = c_patch_w.wv[j][lane];
     }
     auto fetch_patch = [&](int ls, uint32_t (&tmp)[PAT_REGS], uint32_t &ox) {
         const uint32_t xy = __builtin_amdgcn_readfirstlane(s_xy[ls]);
@@ -434,6 +439,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         for (int j = 0; j < PAT_REGS; j++)  // rows and pitch are below 2^13
             tmp[j] = *reinterpret_cast<const uint32_t *>(src + (__umul24(DESC_EXP_ROW(prow[j]), (uint32_t)pitch) + pcol[j]));
     };
+    // Every earlier load has landed here (the weights among them).  Without this statement the compiler waits for
+    // the weights inside the loop, at their first use, and that wait covers the loads just issued for the next
+    // keypoint as well: every keypoint would then pay a whole memory round trip.
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
     uint32_t pt[PAT_REGS], pox = 0;
     if (nmine > 0)
         fetch_patch(wv * DESC_KPW, pt, pox);
