@@ -152,11 +152,12 @@ def main():
     if args.pcie_only:
         print(json.dumps(pcie_inclusive(orbx, torch, host, w, h, nfeat, local_rank, instances=args.pcie_instances)))
         return
-    # The host-memory measurement comes first on a single GPU: its two instances then get hardware queues of
-    # their own.  After the streams of the main measurement have existed (even closed), their streams share
-    # queues and upload and extraction of the two instances no longer overlap (46-59 k instead of 100 k frames/s).
+    # The host-memory measurement (rank 0's own business) comes first: its two instances then get hardware
+    # queues of their own.  After the streams of the main measurement have existed (even closed), their streams
+    # share queues and upload and extraction of the two instances no longer overlap (46-59 k instead of 100 k
+    # frames/s).  The other ranks meanwhile wait at the first barrier.
     pcie_first = None
-    if not args.no_pcie and world == 1:
+    if not args.no_pcie and rank == 0:
         pcie_first = pcie_inclusive(orbx, torch, host, w, h, nfeat, local_rank, instances=args.pcie_instances)
     frames = torch.from_numpy(host).cuda()
     # A stereo pair batch: left and right images go through separate extractor instances on separate
