@@ -284,7 +284,7 @@ static void free_buffers(orbx_extractor *ex)
 {
     OrbxBuffers &b = ex->buf;
     void *ptrs[] = {b.pyr,       b.blur,    b.cell_flag, b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
-                    b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_desc, b.out_n,   b.status,   ex->d_xtab,
+                    b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n,   ex->d_xtab,
                     ex->d_ytab};
     for (void *p : ptrs)
         if (p)
@@ -387,10 +387,17 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     if (e == hipSuccess) e = dmalloc(&b.kept_xy, B * g.kp_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.kept_resp, B * g.kp_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.nkept, B * g.nlevels);
-    if (e == hipSuccess) e = dmalloc(&b.out_kp, B * g.out_cap);
-    if (e == hipSuccess) e = dmalloc(&b.out_desc, B * g.out_cap * 32);
-    if (e == hipSuccess) e = dmalloc(&b.out_n, B);
-    if (e == hipSuccess) e = dmalloc(&b.status, (size_t)ORBX_ST_COUNT);
+    // The descriptors lie behind the keypoint records and the status words behind the counts, each pair in one
+    // allocation: a handle for single frames (max_batch 1) then fetches a frame's results with two copies, not four.
+    // (out_cap is a multiple of 4, so the descriptor rows start 16-byte aligned.)
+    if (e == hipSuccess) {
+        uint8_t *both = nullptr;
+        e = dmalloc(&both, B * g.out_cap * (sizeof(orbx_keypoint) + 32));
+        b.out_kp = reinterpret_cast<orbx_keypoint *>(both);
+        b.out_desc = both ? both + B * g.out_cap * sizeof(orbx_keypoint) : nullptr;
+    }
+    if (e == hipSuccess) e = dmalloc(&b.out_n, B + ORBX_ST_COUNT);
+    b.status = b.out_n ? b.out_n + B : nullptr;
     int xt = 0, yt = 0;
     for (int l = 0; l < g.nlevels; l++)
         xt += align_up(g.lv[l].w, 4), yt += align_up(g.lv[l].h, 2);
@@ -517,7 +524,9 @@ static int run_pipeline(orbx_extractor *ex)
     // The blur only needs the pyramid: it runs on the second stream beside detection and
     // distribution.  While profiling, every stage runs on the main stream so that the stage times
     // are exclusive; "fast" and "blur" then bracket exactly one kernel each.
-    const bool overlap = !ex->profiling;
+    // (one or two frames: the two event records and waits cost the host more than the blur's 10 us beside the
+    // detection save, and a single call is bound by the time the host needs to enqueue it)
+    const bool overlap = !ex->profiling && g.batch > 2;
     hipStream_t s2 = overlap ? ex->aux_stream : s;
     HIP_TRY(hipMemsetAsync(b.status, 0, ORBX_ST_COUNT * sizeof(int), s));
     HIP_TRY(orbx_launch_fast(g, b, s, 0));
@@ -886,12 +895,20 @@ extern "C" int orbx_extract(orbx_extractor *ex, const uint8_t *image, int width,
     int *head = reinterpret_cast<int *>(ex->h_out + (kp_bytes + de_bytes) * (size_t)ex->p.max_batch);
     static_assert((1 + ORBX_ST_COUNT) * sizeof(int) <= 256, "header of the staging buffer");
     uint8_t *h_kp = ex->h_out, *h_de = ex->h_out + kp_bytes;
-    HIP_TRY(hipMemcpyAsync(head, ex->buf.out_n, sizeof(int), hipMemcpyDeviceToHost, ex->stream));
-    HIP_TRY(hipMemcpyAsync(head + 1, ex->buf.status, sizeof(int) * ORBX_ST_COUNT, hipMemcpyDeviceToHost, ex->stream));
-    if (keypoints)
-        HIP_TRY(hipMemcpyAsync(h_kp, ex->buf.out_kp, kp_bytes, hipMemcpyDeviceToHost, ex->stream));
-    if (descriptors)
-        HIP_TRY(hipMemcpyAsync(h_de, ex->buf.out_desc, de_bytes, hipMemcpyDeviceToHost, ex->stream));
+    if (ex->p.max_batch == 1) {
+        // count and status words are neighbours, and so are the frame's keypoint and descriptor rows
+        HIP_TRY(hipMemcpyAsync(head, ex->buf.out_n, sizeof(int) * (1 + ORBX_ST_COUNT), hipMemcpyDeviceToHost, ex->stream));
+        if (keypoints || descriptors)
+            HIP_TRY(hipMemcpyAsync(h_kp, ex->buf.out_kp, kp_bytes + (descriptors ? de_bytes : 0), hipMemcpyDeviceToHost,
+                                   ex->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(head, ex->buf.out_n, sizeof(int), hipMemcpyDeviceToHost, ex->stream));
+        HIP_TRY(hipMemcpyAsync(head + 1, ex->buf.status, sizeof(int) * ORBX_ST_COUNT, hipMemcpyDeviceToHost, ex->stream));
+        if (keypoints)
+            HIP_TRY(hipMemcpyAsync(h_kp, ex->buf.out_kp, kp_bytes, hipMemcpyDeviceToHost, ex->stream));
+        if (descriptors)
+            HIP_TRY(hipMemcpyAsync(h_de, ex->buf.out_desc, de_bytes, hipMemcpyDeviceToHost, ex->stream));
+    }
     HIP_TRY(hipStreamSynchronize(ex->stream));
     if (head[1 + ORBX_ST_CAND_OVERFLOW] || head[1 + ORBX_ST_NODE_OVERFLOW])
         return ORBX_E_CAPACITY;
