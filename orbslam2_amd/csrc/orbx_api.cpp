@@ -76,7 +76,8 @@ struct orbx_extractor {
     float st_mb, st_mbf;
     OrbxXCoef *d_xtab;
     OrbxYCoef *d_ytab;
-    int xtab_cap, ytab_cap;
+    int *d_ptab;
+    int xtab_cap, ytab_cap, ptab_cap;
     std::vector<int> h_counts, h_nkept;
     bool profiling;
     std::vector<hipEvent_t> prof_events;  // 2*ORBX_NSTAGES events (start, end of each stage) per profiled batch
@@ -146,7 +147,7 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
     g->min_th = ex->p.min_th_fast;
     g->blur_variant = ex->p.blur_variant;
     long long off = 0;
-    int cells = 0, tiles = 0, ftiles = 0, cand = 0, kps = 0, xt = 0, yt = 0;
+    int cells = 0, tiles = 0, ftiles = 0, cand = 0, kps = 0, xt = 0, yt = 0, pt = 0;
     for (int l = 0; l < g->nlevels; l++) {
         OrbxLevel &L = g->lv[l];
         L.w = round_half_even((float)w * ex->inv[l]);
@@ -202,6 +203,14 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
         L.patch_size = (int)(31 * ex->sf[l]);
         L.xtab_off = xt;
         L.ytab_off = yt;
+        L.pcol_off = L.prow_off = 0;
+        if (l >= 2) {
+            const OrbxLevel &M = g->lv[l - 1];
+            L.pcol_off = pt;
+            pt += (M.w + ORBX_RS2_TW - 1) / ORBX_RS2_TW + 1;
+            L.prow_off = pt;
+            pt += (M.h + ORBX_RS2_TH - 1) / ORBX_RS2_TH + 1;
+        }
         xt += align_up(L.w, 4);  // a thread reads the coefficients of 4 columns / 2 rows at once
         yt += align_up(L.h, 2);
     }
@@ -216,10 +225,12 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
 }
 
 // cv::resize INTER_LINEAR coefficient tables (8-bit path: 11-bit fixed point, half-to-even rounding)
-static void build_resize_tables(const OrbxGeom &g, std::vector<OrbxXCoef> &xt, std::vector<OrbxYCoef> &yt)
+static void build_resize_tables(const OrbxGeom &g, std::vector<OrbxXCoef> &xt, std::vector<OrbxYCoef> &yt,
+                                std::vector<int> &pt)
 {
     xt.clear();
     yt.clear();
+    pt.clear();
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &D = g.lv[l];
         const size_t x0 = xt.size(), y0 = yt.size();
@@ -271,6 +282,24 @@ static void build_resize_tables(const OrbxGeom &g, std::vector<OrbxXCoef> &xt, s
             xt[x0 + i] = xt[x0 + D.w - 1];
         for (int i = D.h; i < align_up(D.h, 2); i++)
             yt[y0 + i] = yt[y0 + D.h - 1];
+        if (l >= 2) {
+            // fused pairs: the first column (row) of this level whose left (upper) source pixel lies in or
+            // behind tile column (row) t of the level below; source positions ascend with the destination
+            const int ntx = (S.w + ORBX_RS2_TW - 1) / ORBX_RS2_TW, nty = (S.h + ORBX_RS2_TH - 1) / ORBX_RS2_TH;
+            pt.resize(std::max<size_t>(pt.size(), (size_t)D.prow_off + nty + 1));
+            int dx = 0;
+            for (int t = 0; t <= ntx; t++) {
+                while (dx < D.w && xt[x0 + dx].sx < t * ORBX_RS2_TW)
+                    dx++;
+                pt[D.pcol_off + t] = t == ntx ? D.w : dx;
+            }
+            int dy = 0;
+            for (int t = 0; t <= nty; t++) {
+                while (dy < D.h && yt[y0 + dy].sy0 < t * ORBX_RS2_TH)
+                    dy++;
+                pt[D.prow_off + t] = t == nty ? D.h : dy;
+            }
+        }
     }
 }
 
@@ -284,7 +313,7 @@ static void free_buffers(orbx_extractor *ex)
 {
     OrbxBuffers &b = ex->buf;
     void *ptrs[] = {b.pyr,       b.blur,    b.cell_flag, b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
-                    b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n,   ex->d_xtab,
+                    b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n,   ex->d_ptab, ex->d_xtab,
                     ex->d_ytab};
     for (void *p : ptrs)
         if (p)
@@ -302,6 +331,7 @@ static void free_buffers(orbx_extractor *ex)
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
+    ex->d_ptab = nullptr;
 }
 
 extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor **out)
@@ -347,6 +377,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     memset(&ex->buf, 0, sizeof(ex->buf));
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
+    ex->d_ptab = nullptr;
     scale_tables(ex);
     int rc = build_geometry(ex, p.max_width, p.max_height, p.max_batch, &ex->cap_geom);
     if (rc == ORBX_E_GEOMETRY) {
@@ -403,8 +434,12 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
         xt += align_up(g.lv[l].w, 4), yt += align_up(g.lv[l].h, 2);
     ex->xtab_cap = xt;
     ex->ytab_cap = yt;
+    ex->ptab_cap = 0;
+    for (int l = 2; l < g.nlevels; l++)
+        ex->ptab_cap = std::max(ex->ptab_cap, g.lv[l].prow_off + (g.lv[l - 1].h + ORBX_RS2_TH - 1) / ORBX_RS2_TH + 1);
     if (e == hipSuccess) e = dmalloc(&ex->d_xtab, (size_t)xt);
     if (e == hipSuccess) e = dmalloc(&ex->d_ytab, (size_t)yt);
+    if (e == hipSuccess) e = dmalloc(&ex->d_ptab, (size_t)ex->ptab_cap);
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         free_buffers(ex);
@@ -418,6 +453,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     }
     b.xtab = ex->d_xtab;
     b.ytab = ex->d_ytab;
+    b.ptab = ex->d_ptab;
     *out = ex;
     return ORBX_OK;
 }
@@ -500,13 +536,16 @@ static int prepare(orbx_extractor *ex, int batch, int w, int h)
         g.out_cap = c.out_cap;
         std::vector<OrbxXCoef> xt;
         std::vector<OrbxYCoef> yt;
-        build_resize_tables(g, xt, yt);
-        if ((int)xt.size() > ex->xtab_cap || (int)yt.size() > ex->ytab_cap)
+        std::vector<int> pt;
+        build_resize_tables(g, xt, yt, pt);
+        if ((int)xt.size() > ex->xtab_cap || (int)yt.size() > ex->ytab_cap || (int)pt.size() > ex->ptab_cap)
             return ORBX_E_CAPACITY;
         // the previous batch may still read the old tables
         HIP_TRY(hipStreamSynchronize(ex->stream));
         HIP_TRY(hipMemcpy(ex->d_xtab, xt.data(), xt.size() * sizeof(OrbxXCoef), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ex->d_ytab, yt.data(), yt.size() * sizeof(OrbxYCoef), hipMemcpyHostToDevice));
+        if (!pt.empty())
+            HIP_TRY(hipMemcpy(ex->d_ptab, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
         ex->geom = g;
         ex->geom_w = w;
         ex->geom_h = h;
@@ -531,8 +570,20 @@ static int run_pipeline(orbx_extractor *ex)
     HIP_TRY(hipMemsetAsync(b.status, 0, ORBX_ST_COUNT * sizeof(int), s));
     HIP_TRY(orbx_launch_fast(g, b, s, 0));
     HIP_TRY(prof_mark(ex, 1, 0, s));
-    for (int l = 1; l < g.nlevels; l++)
-        HIP_TRY(orbx_launch_resize(l, g, b, s));
+    // A few frames: pairs of levels in one launch (four launches instead of seven; the time of such a call is
+    // mostly launches).  Batches: a launch per level, which is faster there (the fused kernel computes 5 % of
+    // the middle level twice and is bound by its instruction count).  The fused kernel's margins hold for level
+    // ratios up to 2.5.
+    for (int l = 1; l < g.nlevels;) {
+        if (g.batch <= 4 && l + 1 < g.nlevels && 2 * g.lv[l].w <= 5 * g.lv[l + 1].w &&
+            2 * g.lv[l].h <= 5 * g.lv[l + 1].h) {
+            HIP_TRY(orbx_launch_resize_pair(l, g, b, s));
+            l += 2;
+        } else {
+            HIP_TRY(orbx_launch_resize(l, g, b, s));
+            l += 1;
+        }
+    }
     HIP_TRY(prof_mark(ex, 1, 1, s));
     if (overlap) {
         HIP_TRY(hipEventRecord(ex->ev_pyramid, s));

@@ -16,6 +16,9 @@
 // blur tile produced by one workgroup
 #define ORBX_FT_W 128
 #define ORBX_FT_H 32
+// fused resize of two levels: columns / rows of the middle level a workgroup owns (it computes 256 x 32)
+#define ORBX_RS2_TW 252
+#define ORBX_RS2_TH 31
 // FAST tile produced by one workgroup
 #define ORBX_FAST_W 64
 #define ORBX_FAST_H 64
@@ -40,6 +43,9 @@ struct OrbxLevel {
     float scale;     // mvScaleFactor[level]
     int patch_size;  // (int)(31*scale)
     int xtab_off, ytab_off;  // offsets into the resize coefficient tables
+    // the level as the upper one of a fused resize pair: offsets (into the pair table) of the first column /
+    // row of this level that each tile column / row of the level below produces (one entry more than tiles)
+    int pcol_off, prow_off;
 };
 
 struct OrbxGeom {
@@ -94,6 +100,7 @@ struct OrbxBuffers {
     int *status;            // [ORBX_ST_COUNT]
     const OrbxXCoef *xtab;
     const OrbxYCoef *ytab;
+    const int *ptab;  // pair table of the fused resize (OrbxLevel::pcol_off, prow_off)
 };
 
 // kernel launchers (each enqueues on `s` and returns the hipGetLastError code)
@@ -150,6 +157,8 @@ __device__ __forceinline__ int orbx_wave_scan_add_i32(int v)
 hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, const OrbxGeom &g, const OrbxBuffers &b,
                               hipStream_t s);
 hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+// levels `level` and `level + 1` from level `level - 1` in one launch
+hipError_t orbx_launch_resize_pair(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s, int part);
 hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);

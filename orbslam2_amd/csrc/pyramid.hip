@@ -52,24 +52,19 @@ typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
 // factor up to 2), a source row costs one 12-byte load from the aligned word below the first pixel,
 // two byte alignments that bring the first pixel to byte 0, and per pixel one byte permute (the two
 // neighbours as a 2 x u16 vector) and one 2 x u16 dot product with the packed coefficient pair.  Lanes
-// whose 12 bytes would end behind `src_bytes` (the readable bytes of a frame) take the byte-wise path.
-__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_lvl, long long src_fstride,
-                                                uint32_t src_bytes, uint8_t *__restrict__ pyr_out, int slab, int spitch,
-                                                int doff, int dpitch, int dw, int dh,
-                                                const OrbxXCoef *__restrict__ xt, const OrbxYCoef *__restrict__ yt)
+// whose 12 bytes would end behind `src_bytes` (the readable bytes of the source) take the byte-wise path.
+//
+// resize_rows: destination rows dy0 .. dy1-1 (wave-uniform) of the lane's columns dx0 .. dx0+3.  `sbase`
+// points at source pixel (0, 0) (global memory or LDS); `put(dy, word)` receives the four result bytes of a row.
+template <typename Put>
+__device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, uint32_t src_bytes, int dx0, int dy0,
+                                            int dy1, const OrbxXCoef *__restrict__ xt,
+                                            const OrbxYCoef *__restrict__ yt, Put put)
 {
-    const int f = blockIdx.z;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS);
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (dy0 >= dh || dx0 >= dw)
-        return;
-    const int dy1 = min(dy0 + RS_ROWS, dh);
     // the column table is padded to a multiple of 4 columns with copies of the last entry
     const uint4 t0 = *reinterpret_cast<const uint4 *>(xt + dx0), t1 = *reinterpret_cast<const uint4 *>(xt + dx0 + 2);
     const int sx[4] = {(int)t0.x, (int)t0.z, (int)t1.x, (int)t1.z};
     const uint32_t coef[4] = {t0.y, t0.w, t1.y, t1.w};  // a0 | a1 << 16
-    const uint8_t *sbase = src_lvl + (size_t)f * src_fstride;
-    uint8_t *dbase = pyr_out + (size_t)f * slab + doff;
     const uint32_t wb = (uint32_t)sx[0] & ~3u;  // aligned byte offset of the first word
     const uint32_t s0 = (uint32_t)sx[0] & 3u;
     const uint32_t last_row = (uint32_t)yt[dy1 - 1].sy1;  // source rows ascend with the destination row
@@ -145,15 +140,107 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_
                 const rs_pk sum = __builtin_bit_cast(rs_pk, t) + __builtin_bit_cast(rs_pk, u) + (rs_pk){2, 2};
                 return __builtin_bit_cast(uint32_t, (rs_pk)(sum >> (rs_pk){2, 2}));
             };
-            const uint32_t out = __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u);  // the four low bytes
-            *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy, dpitch) + dx0)) = out;
+            put(dy, __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u));  // the four low bytes
             if (++dy < dy1)
-                c = yt[dy];
+                c = yt[__builtin_amdgcn_readfirstlane(dy)];  // the row is the wave's: a scalar load
         }
 #pragma unroll
         for (int i = 0; i < 4; i++)
             prev[i] = cur[i];
     }
+}
+
+__global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_lvl, long long src_fstride,
+                                                uint32_t src_bytes, uint8_t *__restrict__ pyr_out, int slab, int spitch,
+                                                int doff, int dpitch, int dw, int dh,
+                                                const OrbxXCoef *__restrict__ xt, const OrbxYCoef *__restrict__ yt)
+{
+    const int f = blockIdx.z;
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS);
+    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    if (dy0 >= dh || dx0 >= dw)
+        return;
+    uint8_t *dbase = pyr_out + (size_t)f * slab + doff;
+    resize_rows(src_lvl + (size_t)f * src_fstride, spitch, src_bytes, dx0, dy0, min(dy0 + RS_ROWS, dh), xt, yt,
+                [&](int dy, uint32_t out) {
+                    *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy, dpitch) + dx0)) = out;
+                });
+}
+
+// ---- two levels in one launch (calls of a few frames, whose time is mostly launches) ----
+// A workgroup computes 256 x 32 pixels of the middle level (from global memory, as above), writes them out and
+// keeps them in LDS; it owns 252 x 31 of them (the last four columns and the last row are computed again by the
+// neighbours that own them, so that every pixel of the upper level has both its source columns and both its
+// source rows inside the tile that holds the left / upper one).  Then it computes from LDS the pixels of the
+// upper level whose left / upper source pixel it owns: columns pcol[tx] .. pcol[tx + 1] - 1, rows
+// prow[ty] .. prow[ty + 1] - 1 (tables from the host).  Lanes take aligned groups of four columns as before; a
+// group that straddles the tile's first or last column stores its own bytes only.  Four launches per pyramid
+// instead of seven; for batches the plain kernel is faster (this one is bound by its instruction count and
+// computes 5 % of the middle level twice).
+#define RS2_PAD 16     // readable bytes left of the staged columns (groups of the upper level that start before the tile)
+#define RS2_PITCH 304  // 16 + 256 + 32 (what a group that ends behind the tile may touch at a level ratio up to 2.5)
+__global__ __launch_bounds__(256) void k_resize_pair(const uint8_t *__restrict__ src_lvl, long long src_fstride,
+                                                     uint32_t src_bytes, uint8_t *__restrict__ pyr_out, int slab,
+                                                     int spitch, int moff, int mpitch, int mw, int mh,
+                                                     const OrbxXCoef *__restrict__ mxt, const OrbxYCoef *__restrict__ myt,
+                                                     int toff, int tpitch, const OrbxXCoef *__restrict__ txt,
+                                                     const OrbxYCoef *__restrict__ tyt, const int *__restrict__ pcol,
+                                                     const int *__restrict__ prow)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t mid[32 * RS2_PITCH];
+    const int f = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int X1 = blockIdx.x * ORBX_RS2_TW, Y1 = blockIdx.y * ORBX_RS2_TH;
+    {
+        const int dx0 = X1 + 4 * lane;
+        const int dy0 = __builtin_amdgcn_readfirstlane(Y1 + RS_ROWS * wv);
+        if (dy0 < mh && dx0 < mw) {
+            uint8_t *dbase = pyr_out + (size_t)f * slab + moff;
+            uint8_t *lbase = mid + RS2_PAD + 4 * lane;
+            resize_rows(src_lvl + (size_t)f * src_fstride, spitch, src_bytes, dx0, dy0, min(dy0 + RS_ROWS, mh), mxt, myt,
+                        [&](int dy, uint32_t out) {
+                            *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy, mpitch) + dx0)) = out;
+                            *reinterpret_cast<uint32_t *>(lbase + __umul24(dy - Y1, RS2_PITCH)) = out;
+                        });
+        }
+    }
+    __syncthreads();
+    const int x2a = pcol[blockIdx.x], x2b = pcol[blockIdx.x + 1];
+    const int y2a = prow[blockIdx.y], y2b = prow[blockIdx.y + 1];
+    const int gx0 = (x2a & ~3) + 4 * lane;
+    const int ry0 = __builtin_amdgcn_readfirstlane(y2a + RS_ROWS * wv);
+    if (ry0 < y2b && gx0 < x2b) {
+        uint8_t *tbase = pyr_out + (size_t)f * slab + toff;
+        const bool whole = gx0 >= x2a && gx0 + 4 <= x2b;
+        // LDS address of middle-level pixel (0, 0): pixel (X, Y) lies at mid[(Y - Y1) * RS2_PITCH + RS2_PAD + X - X1]
+        const uint8_t *origin = mid + RS2_PAD - X1 - Y1 * RS2_PITCH;
+        resize_rows(origin, RS2_PITCH, 0xffffffffu, gx0, ry0, min(ry0 + RS_ROWS, y2b), txt, tyt, [&](int dy, uint32_t out) {
+            uint8_t *d = tbase + (uint32_t)(__umul24(dy, tpitch) + gx0);
+            if (whole) {
+                *reinterpret_cast<uint32_t *>(d) = out;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (gx0 + i >= x2a && gx0 + i < x2b)
+                        d[i] = (uint8_t)(out >> (8 * i));
+            }
+        });
+    }
+}
+
+hipError_t orbx_launch_resize_pair(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
+{
+    const OrbxLevel &S = g.lv[level - 1];
+    const OrbxLevel &M = g.lv[level];
+    const OrbxLevel &T = g.lv[level + 1];
+    dim3 grid((M.w + ORBX_RS2_TW - 1) / ORBX_RS2_TW, (M.h + ORBX_RS2_TH - 1) / ORBX_RS2_TH, g.batch);
+    const uint8_t *src = level == 1 ? b.l0.ptr : b.pyr + S.off;
+    const long long sfs = level == 1 ? b.l0.fstride : (long long)g.slab;
+    const int spitch = level == 1 ? b.l0.pitch : S.pitch;
+    const uint32_t src_bytes = (uint32_t)spitch * (uint32_t)S.h + (level == 1 ? 0u : 16u);
+    k_resize_pair<<<grid, 256, 0, s>>>(src, sfs, src_bytes, b.pyr, g.slab, spitch, M.off, M.pitch, M.w, M.h,
+                                       b.xtab + M.xtab_off, b.ytab + M.ytab_off, T.off, T.pitch, b.xtab + T.xtab_off,
+                                       b.ytab + T.ytab_off, b.ptab + T.pcol_off, b.ptab + T.prow_off);
+    return hipGetLastError();
 }
 
 hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
