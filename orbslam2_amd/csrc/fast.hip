@@ -164,8 +164,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     while (lvl + 1 < a.nlevels && unit >= a.tile_base[lvl + 1])
         lvl++;
     const int t = unit - a.tile_base[lvl];
-    const int tx0 = (t % a.tiles_x[lvl]) * ORBX_FAST_W;
-    const int ty0 = (t / a.tiles_x[lvl]) * ORBX_FAST_H;
+    const int tx0 = ORBX_FAST_X0 + (t % a.tiles_x[lvl]) * ORBX_FAST_W;
+    const int ty0 = ORBX_FAST_Y0 + (t / a.tiles_x[lvl]) * ORBX_FAST_H;
     const int w = a.w[lvl], h = a.h[lvl], pitch = lvl == 0 ? a.l0.pitch : a.pitch[lvl];
     const int wc = a.wcell[lvl], hc = a.hcell[lvl];
     const int x_lo = ORBX_CELL_ORG, x_hi = w - ORBX_CELL_ORG, y_lo = ORBX_CELL_ORG, y_hi = h - ORBX_CELL_ORG;

@@ -177,8 +177,8 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
         L.tiles_y = (L.h + ORBX_FT_H - 1) / ORBX_FT_H;
         L.tile_base = tiles;
         tiles += L.tiles_x * L.tiles_y;
-        L.ftiles_x = (L.w + ORBX_FAST_W - 1) / ORBX_FAST_W;
-        L.ftiles_y = (L.h + ORBX_FAST_H - 1) / ORBX_FAST_H;
+        L.ftiles_x = ORBX_FAST_TILES_X(L.w);
+        L.ftiles_y = ORBX_FAST_TILES_Y(L.h);
         L.ftile_base = ftiles;
         ftiles += L.ftiles_x * L.ftiles_y;
         L.cand_base = cand;

@@ -19,9 +19,14 @@
 // fused resize of two levels: columns / rows of the middle level a workgroup owns (it computes 256 x 32)
 #define ORBX_RS2_TW 252
 #define ORBX_RS2_TH 31
-// FAST tile produced by one workgroup
+// FAST tile produced by one workgroup.  The tile grid starts at (16, 19): FAST reports pixels of
+// [19, w-19) x [19, h-19) only, and a column origin of 16 keeps the 16-byte pieces of the staging aligned.
 #define ORBX_FAST_W 64
 #define ORBX_FAST_H 64
+#define ORBX_FAST_X0 16
+#define ORBX_FAST_Y0 ORBX_CELL_ORG
+#define ORBX_FAST_TILES_X(w) ((w) - ORBX_CELL_ORG - ORBX_FAST_X0 > 0 ? ((w) - ORBX_CELL_ORG - ORBX_FAST_X0 + ORBX_FAST_W - 1) / ORBX_FAST_W : 1)
+#define ORBX_FAST_TILES_Y(h) ((h) - ORBX_CELL_ORG - ORBX_FAST_Y0 > 0 ? ((h) - ORBX_CELL_ORG - ORBX_FAST_Y0 + ORBX_FAST_H - 1) / ORBX_FAST_H : 1)
 // A FAST tile holds at most 34 x 34 strict per-cell local maxima (one per 2x2 pixels of a cell,
 // cells at least 30 px wide): capacity of a tile's candidate list
 #define ORBX_TILE_CAP 1160

@@ -70,8 +70,8 @@ int main(int argc, char **argv)
         a.wcell[l] = (int)ceilf(width / nc), a.hcell[l] = (int)ceilf(height / nr);
         a.cell_base[l] = cells;
         cells += nc * nr;
-        a.tile_base[l] = tiles, a.tiles_x[l] = (w + ORBX_FAST_W - 1) / ORBX_FAST_W;
-        tiles += a.tiles_x[l] * ((h + ORBX_FAST_H - 1) / ORBX_FAST_H);
+        a.tile_base[l] = tiles, a.tiles_x[l] = ORBX_FAST_TILES_X(w);
+        tiles += a.tiles_x[l] * ORBX_FAST_TILES_Y(h);
         a.cand_base[l] = cand, a.cand_cap[l] = align_up(w * h / 4 + 4, 4);
         cand += a.cand_cap[l];
         a.wc_magic[l] = ((1u << 20) + a.wcell[l] - 1) / a.wcell[l];
