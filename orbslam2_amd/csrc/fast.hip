@@ -187,19 +187,21 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     // a thread keeps one word column (of the 18 that matter) and walks down the rows in steps of 14
     const int g = threadIdx.x % GRP_W, r0 = threadIdx.x / GRP_W;
     const bool walker = threadIdx.x < 14 * GRP_W;
-    // stage rows ty0-4 .. ty0+67; whole 16-byte pieces where the tile lies inside the level
-    const bool inside = tx0 >= IMG_X0 && tx0 + IMG_W - IMG_X0 <= pitch && ty0 >= 4 && ty0 + ORBX_FAST_H + 4 <= h &&
-                        (pitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
-    if (inside) {
+    // Stage rows ty0-4 .. ty0+67 in whole 16-byte pieces (the tile grid starts at column 16 and row 19, so the
+    // staged window never begins outside the level).  Only pixels up to 3 around the detectable range are ever
+    // read: rows from y_hi + 3 on and pieces behind the row pitch stay unstaged.
+    const bool aligned = (pitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
+    const int nrows = min(IMG_H, y_hi + 3 - (ty0 - 4));                       // staged rows 0 .. nrows-1
+    const int npieces = min(IMG_W / 16, (pitch - (tx0 - IMG_X0)) >> 4);        // pieces 0 .. npieces-1 of a row
+    if (aligned) {
         const uint8_t *s0 = src + (size_t)(ty0 - 4) * pitch + (tx0 - IMG_X0);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int i = threadIdx.x + 256 * k;  // 72 rows x 6 pieces = 432 items
-            if (i < IMG_H * (IMG_W / 16)) {
-                const int r = i / (IMG_W / 16), c = i % (IMG_W / 16);
+            const int r = i / (IMG_W / 16), c = i % (IMG_W / 16);
+            if (r < nrows && c < npieces)
                 *reinterpret_cast<uint4 *>(&img[r * IMG_W + 16 * c]) =
                     *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(r, pitch) + 16 * c));
-            }
         }
     } else if (walker) {
         const int x = tx0 - 4 + 4 * g;
