@@ -71,23 +71,55 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const uint32_t t2a = k0 << 24, t2b = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), t2c = k1 | (k0 << 8);
     const uint32_t t3b = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), t3c = k2 | (k1 << 8) | (k0 << 16);
 
-    // interior: every needed pixel (3 around the tile) exists and whole 16-byte pieces can be read
-    const bool interior = tx0 >= BL_LEFT && tx0 + BL_W + 3 <= w && tx0 + BL_W + 16 <= spitch && ty0 >= 3 &&
-                          ty0 + BL_H + 3 <= h && (spitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
-    if (interior) {
-        const uint8_t *s0 = src + (size_t)(ty0 - 3) * spitch + (tx0 - BL_LEFT);
+    // Staging in whole 16-byte pieces wherever the level is 16-byte aligned.  interior: every needed pixel (3
+    // around the tile) exists.  Other tiles mirror the rows outside the image (reflect 101: a staged row is a
+    // source row, the same for the whole row), skip the pieces left of column 0 or behind the row pitch, and
+    // afterwards patch the three columns left of the image and the three right of it byte by byte.  Nearly half
+    // of the tiles of a pyramid touch a border, so they must not cost more than this.
+    const bool aligned = (spitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
+    const bool interior = aligned && tx0 >= BL_LEFT && tx0 + BL_W + 3 <= w && tx0 + BL_W + 16 <= spitch && ty0 >= 3 &&
+                          ty0 + BL_H + 3 <= h;
+    if (aligned) {
+        // readable bytes of the level: a caller's level-0 buffer may end with the last row's pixels
+        const uint32_t src_bytes = (uint32_t)spitch * (uint32_t)(h - 1) + (uint32_t)(lvl == 0 ? w : spitch);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int i = threadIdx.x + 256 * k;  // 38 rows x 10 pieces = 380 items
             if (i < BL_SH * (BL_SWORDS / 4)) {
                 const int r = i / (BL_SWORDS / 4), c = i % (BL_SWORDS / 4);
-                *reinterpret_cast<uint4 *>(&img[r * BL_SWORDS + 4 * c]) =
-                    *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(r, spitch) + 16 * c));
+                const int x0 = tx0 - BL_LEFT + 16 * c;
+                const int sy = interior ? ty0 - 3 + r : reflect101(ty0 - 3 + r, h);
+                if (interior || (x0 >= 0 && x0 + 16 <= spitch)) {
+                    const uint32_t o = (uint32_t)(__umul24(sy, spitch) + x0);
+                    uint4 v;
+                    if (interior || o + 16u <= src_bytes) {
+                        v = *reinterpret_cast<const uint4 *>(src + o);
+                    } else {
+                        // the last pieces of the last row: pixels only
+                        uint32_t q[4] = {0, 0, 0, 0};
+                        for (int b = 0; b < 16; b++)
+                            if (x0 + b < w)
+                                q[b >> 2] |= (uint32_t)src[o + b] << (8 * (b & 3));
+                        v = make_uint4(q[0], q[1], q[2], q[3]);
+                    }
+                    *reinterpret_cast<uint4 *>(&img[r * BL_SWORDS + 4 * c]) = v;
+                }
+            }
+        }
+        if (!interior) {
+            __syncthreads();
+            if (threadIdx.x < BL_SH * 6) {
+                const int r = threadIdx.x / 6, k = threadIdx.x % 6;
+                const int x = k < 3 ? -1 - k : w + k - 3;
+                const int col = x - (tx0 - BL_LEFT);  // staged byte column
+                if (col >= 0 && col < 4 * BL_SWORDS)
+                    reinterpret_cast<uint8_t *>(img)[r * (4 * BL_SWORDS) + col] =
+                        src[(uint32_t)__umul24(reflect101(ty0 - 3 + r, h), spitch) + reflect101(x, w)];
             }
         }
     } else {
-        // edge tile: rows and columns outside the image mirror about the border pixel (reflect 101);
-        // words that lie inside the row are still loaded whole.  Only words 3 .. 36 of a staged row
+        // unaligned level (a caller's level 0 at an odd address or pitch): rows and columns outside the image
+        // mirror about the border pixel; words that lie inside the row are still loaded whole.  Only words 3 .. 36 of a staged row
         // (columns tx0-4 .. tx0+131) are needed.  A thread keeps one word column, so the column's
         // reflected byte offsets are computed once, and walks down the rows.
         const int c4 = threadIdx.x & 63;
