@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     // source row, the same for the whole row), skip the pieces left of column 0 or behind the row pitch, and
     // afterwards patch the three columns left of the image and the three right of it byte by byte.  Nearly half
     // of the tiles of a pyramid touch a border, so they must not cost more than this.
+    // a tile at the bottom of a level holds h - ty0 < 32 rows: only the row pairs those rows read are staged and filtered
+    const int npairs = min(BL_PAIRS, (h - ty0 + 7) >> 1);
     const bool aligned = (spitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
     const bool interior = aligned && tx0 >= BL_LEFT && tx0 + BL_W + 3 <= w && tx0 + BL_W + 16 <= spitch && ty0 >= 3 &&
                           ty0 + BL_H + 3 <= h;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int i = threadIdx.x + 256 * k;  // 38 rows x 10 pieces = 380 items
-            if (i < BL_SH * (BL_SWORDS / 4)) {
+            if (i < 2 * npairs * (BL_SWORDS / 4)) {
                 const int r = i / (BL_SWORDS / 4), c = i % (BL_SWORDS / 4);
                 const int x0 = tx0 - BL_LEFT + 16 * c;
                 const int sy = interior ? ty0 - 3 + r : reflect101(ty0 - 3 + r, h);
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int item = threadIdx.x + 256 * k;  // 19 row pairs x 32 groups = 608 items
-        if (item < BL_PAIRS * BL_GROUPS) {
+        if (item < npairs * BL_GROUPS) {
             const int p = item >> 5, cg = item & 31;
             uint32_t hv[2][4];
 #pragma unroll
