@@ -10,8 +10,6 @@
 struct BlurArgs {
     int nlevels, slab, variant, batch;
     OrbxLevel0 l0;
-    int tile_base[ORBX_MAX_LEVELS + 1];
-    int tiles_x[ORBX_MAX_LEVELS];
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
 };
 
@@ -48,18 +46,19 @@ __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c)
 // Vertical pass: a thread takes 4 pixels of four rows; the 7 taps of a pixel are four 2 x u16 dot
 // products on those row-pair words (the row's parity decides where the zero tap sits).
 template <int VARIANT>  // 0: taps 18 34 48 56 (sum 256), 1: 18 34 49 55 (sum 257)
-__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, BlurArgs a)
+__global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur,
+                                              const uint32_t *__restrict__ tile_tab, BlurArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t img[BL_SH * BL_SWORDS];
     __shared__ __attribute__((aligned(16))) uint32_t hs[BL_PAIRS * BL_W];  // h(row 2p, x) | h(row 2p+1, x) << 16
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
         return;
-    int lvl = 0;
-    while (lvl + 1 < a.nlevels && unit >= a.tile_base[lvl + 1])
-        lvl++;
-    const int t = unit - a.tile_base[lvl];
-    const int tx0 = (t % a.tiles_x[lvl]) * BL_W, ty0 = (t / a.tiles_x[lvl]) * BL_H;
+    // the tile's level, row and column from the host's table: one scalar load instead of a search over the
+    // levels and a division in every wave (scalar instructions are issued at the rate of the slower vector ones)
+    const uint32_t te = tile_tab[unit];
+    const int lvl = te >> 24;
+    const int tx0 = (int)(te & 0xfffu) * BL_W, ty0 = (int)((te >> 12) & 0xfffu) * BL_H;
     const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
     const int spitch = lvl == 0 ? a.l0.pitch : pitch;
     const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
@@ -229,14 +228,12 @@ hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
     a.l0 = b.l0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
-        a.tile_base[l] = L.tile_base, a.tiles_x[l] = L.tiles_x;
         a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
     }
-    a.tile_base[g.nlevels] = g.tiles_per_frame;
     if (g.blur_variant)
-        k_blur<1><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, a);
+        k_blur<1><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, b.tile_tab, a);
     else
-        k_blur<0><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, a);
+        k_blur<0><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, b.tile_tab, a);
     return hipGetLastError();
 }
 

@@ -131,7 +131,6 @@ struct FastArgs {
     OrbxLevel0 l0;
     int t_low, t_ini;  // min(iniThFAST, minThFAST) and iniThFAST, clamped to [1,255]
     int tile_base[ORBX_MAX_LEVELS + 1];
-    int tiles_x[ORBX_MAX_LEVELS];
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
     int wcell[ORBX_MAX_LEVELS], hcell[ORBX_MAX_LEVELS], ncols[ORBX_MAX_LEVELS], cell_base[ORBX_MAX_LEVELS];
     int cand_base[ORBX_MAX_LEVELS], cand_cap[ORBX_MAX_LEVELS];
@@ -146,7 +145,7 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
 
 __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, int *__restrict__ tile_cnt,
                                               uint2 *__restrict__ tile_list, uint8_t *__restrict__ cell_flag,
-                                              FastArgs a)
+                                              const uint32_t *__restrict__ ftile_tab, FastArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[IMG_H * IMG_W];  // staged pixels
     __shared__ __attribute__((aligned(16))) uint8_t sc[SC_H * SC_P];     // A where it exceeds t_low, else 0
@@ -160,12 +159,12 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
         return;
-    int lvl = 0;
-    while (lvl + 1 < a.nlevels && unit >= a.tile_base[lvl + 1])
-        lvl++;
-    const int t = unit - a.tile_base[lvl];
-    const int tx0 = ORBX_FAST_X0 + (t % a.tiles_x[lvl]) * ORBX_FAST_W;
-    const int ty0 = ORBX_FAST_Y0 + (t / a.tiles_x[lvl]) * ORBX_FAST_H;
+    // level, tile row and tile column from the host's table (one scalar load; a search over the levels and a
+    // division in every wave cost as many issue slots as a tenth of the kernel's vector work)
+    const uint32_t te = ftile_tab[unit];
+    const int lvl = te >> 24;
+    const int tx0 = ORBX_FAST_X0 + (int)(te & 0xfffu) * ORBX_FAST_W;
+    const int ty0 = ORBX_FAST_Y0 + (int)((te >> 12) & 0xfffu) * ORBX_FAST_H;
     const int w = a.w[lvl], h = a.h[lvl], pitch = lvl == 0 ? a.l0.pitch : a.pitch[lvl];
     const int wc = a.wcell[lvl], hc = a.hcell[lvl];
     const int x_lo = ORBX_CELL_ORG, x_hi = w - ORBX_CELL_ORG, y_lo = ORBX_CELL_ORG, y_hi = h - ORBX_CELL_ORG;
@@ -357,14 +356,13 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
 __global__ __launch_bounds__(64) void k_gather(const int *__restrict__ tile_cnt, const uint2 *__restrict__ tile_list,
                                                int *__restrict__ ncand, uint32_t *__restrict__ cand_xy,
                                                uint8_t *__restrict__ cand_resp, uint32_t *__restrict__ cand_key,
-                                               int *__restrict__ status, FastArgs a)
+                                               int *__restrict__ status, const uint32_t *__restrict__ ftile_tab,
+                                               FastArgs a)
 {
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
         return;
-    int lvl = 0;
-    while (lvl + 1 < a.nlevels && unit >= a.tile_base[lvl + 1])
-        lvl++;
+    const int lvl = ftile_tab[unit] >> 24;
     const int first = a.tile_base[lvl], ntiles = a.tile_base[lvl + 1] - first;
     const int me = unit - first;
     const int *cnt = tile_cnt + (size_t)f * a.tiles_per_frame + first;
@@ -420,7 +418,6 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.tile_base[l] = L.ftile_base;
-        a.tiles_x[l] = L.ftiles_x;
         a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
         a.wcell[l] = L.wcell, a.hcell[l] = L.hcell, a.ncols[l] = L.ncols, a.cell_base[l] = L.cell_base;
         a.cand_base[l] = L.cand_base, a.cand_cap[l] = L.cand_cap;
@@ -433,9 +430,10 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
                                      : hipSuccess;
     const dim3 grid = orbx_frame_grid(g.ftiles_per_frame, g.batch);
     if (part == 1) {
-        k_fast<<<grid, 256, 0, s>>>(b.pyr, b.tile_cnt, b.tile_list, b.cell_flag, a);
+        k_fast<<<grid, 256, 0, s>>>(b.pyr, b.tile_cnt, b.tile_list, b.cell_flag, b.tile_tab + g.tiles_per_frame, a);
         return hipGetLastError();
     }
-    k_gather<<<grid, 64, 0, s>>>(b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.status, a);
+    k_gather<<<grid, 64, 0, s>>>(b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.status,
+                                 b.tile_tab + g.tiles_per_frame, a);
     return hipGetLastError();
 }

@@ -77,7 +77,8 @@ struct orbx_extractor {
     OrbxXCoef *d_xtab;
     OrbxYCoef *d_ytab;
     int *d_ptab;
-    int xtab_cap, ytab_cap, ptab_cap;
+    uint32_t *d_tiletab;
+    int xtab_cap, ytab_cap, ptab_cap, tiletab_cap;
     std::vector<int> h_counts, h_nkept;
     bool profiling;
     std::vector<hipEvent_t> prof_events;  // 2*ORBX_NSTAGES events (start, end of each stage) per profiled batch
@@ -314,7 +315,7 @@ static void free_buffers(orbx_extractor *ex)
     OrbxBuffers &b = ex->buf;
     void *ptrs[] = {b.pyr,       b.blur,    b.cell_flag, b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
                     b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n,   ex->d_ptab, ex->d_xtab,
-                    ex->d_ytab};
+                    ex->d_ytab,  ex->d_tiletab};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -332,6 +333,7 @@ static void free_buffers(orbx_extractor *ex)
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
     ex->d_ptab = nullptr;
+    ex->d_tiletab = nullptr;
 }
 
 extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor **out)
@@ -378,6 +380,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->d_xtab = nullptr;
     ex->d_ytab = nullptr;
     ex->d_ptab = nullptr;
+    ex->d_tiletab = nullptr;
     scale_tables(ex);
     int rc = build_geometry(ex, p.max_width, p.max_height, p.max_batch, &ex->cap_geom);
     if (rc == ORBX_E_GEOMETRY) {
@@ -440,6 +443,8 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     if (e == hipSuccess) e = dmalloc(&ex->d_xtab, (size_t)xt);
     if (e == hipSuccess) e = dmalloc(&ex->d_ytab, (size_t)yt);
     if (e == hipSuccess) e = dmalloc(&ex->d_ptab, (size_t)ex->ptab_cap);
+    ex->tiletab_cap = g.tiles_per_frame + g.ftiles_per_frame;
+    if (e == hipSuccess) e = dmalloc(&ex->d_tiletab, (size_t)ex->tiletab_cap);
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         free_buffers(ex);
@@ -454,6 +459,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     b.xtab = ex->d_xtab;
     b.ytab = ex->d_ytab;
     b.ptab = ex->d_ptab;
+    b.tile_tab = ex->d_tiletab;
     *out = ex;
     return ORBX_OK;
 }
@@ -540,12 +546,25 @@ static int prepare(orbx_extractor *ex, int batch, int w, int h)
         build_resize_tables(g, xt, yt, pt);
         if ((int)xt.size() > ex->xtab_cap || (int)yt.size() > ex->ytab_cap || (int)pt.size() > ex->ptab_cap)
             return ORBX_E_CAPACITY;
+        // the tiles of a frame in the order of the kernels' unit numbers: blur tiles, then FAST tiles
+        std::vector<uint32_t> tt;
+        for (int l = 0; l < g.nlevels; l++)
+            for (int ty = 0; ty < g.lv[l].tiles_y; ty++)
+                for (int tx = 0; tx < g.lv[l].tiles_x; tx++)
+                    tt.push_back(ORBX_TILE_ENTRY(l, ty, tx));
+        for (int l = 0; l < g.nlevels; l++)
+            for (int ty = 0; ty < g.lv[l].ftiles_y; ty++)
+                for (int tx = 0; tx < g.lv[l].ftiles_x; tx++)
+                    tt.push_back(ORBX_TILE_ENTRY(l, ty, tx));
+        if ((int)tt.size() != g.tiles_per_frame + g.ftiles_per_frame || (int)tt.size() > ex->tiletab_cap)
+            return ORBX_E_CAPACITY;
         // the previous batch may still read the old tables
         HIP_TRY(hipStreamSynchronize(ex->stream));
         HIP_TRY(hipMemcpy(ex->d_xtab, xt.data(), xt.size() * sizeof(OrbxXCoef), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ex->d_ytab, yt.data(), yt.size() * sizeof(OrbxYCoef), hipMemcpyHostToDevice));
         if (!pt.empty())
             HIP_TRY(hipMemcpy(ex->d_ptab, pt.data(), pt.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ex->d_tiletab, tt.data(), tt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         ex->geom = g;
         ex->geom_w = w;
         ex->geom_h = h;

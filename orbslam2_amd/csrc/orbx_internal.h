@@ -106,7 +106,11 @@ struct OrbxBuffers {
     const OrbxXCoef *xtab;
     const OrbxYCoef *ytab;
     const int *ptab;  // pair table of the fused resize (OrbxLevel::pcol_off, prow_off)
+    // level << 24 | tile row << 12 | tile column of every blur tile of a frame (tiles_per_frame entries), then of
+    // every FAST tile (ftiles_per_frame entries): a workgroup finds its tile with one scalar load
+    const uint32_t *tile_tab;
 };
+#define ORBX_TILE_ENTRY(lvl, ty, tx) (((uint32_t)(lvl) << 24) | ((uint32_t)(ty) << 12) | (uint32_t)(tx))
 
 // kernel launchers (each enqueues on `s` and returns the hipGetLastError code)
 // Grids of kernels that work on (unit-of-a-frame, frame) pairs are shaped (gx, units, groups) with

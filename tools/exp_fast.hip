@@ -59,6 +59,7 @@ int main(int argc, char **argv)
     OK(orbx_extract_batch_host(ex, ptrs.data(), 8, W, H, W));
     long long off = 0;
     int cells = 0, tiles = 0, cand = 0;
+    std::vector<uint32_t> tile_tab;
     for (int l = 0; l < NL; l++) {
         int w, h;
         OK(orbx_pyramid_level(ex, 0, l, 0, nullptr, 0, &w, &h));
@@ -70,8 +71,11 @@ int main(int argc, char **argv)
         a.wcell[l] = (int)ceilf(width / nc), a.hcell[l] = (int)ceilf(height / nr);
         a.cell_base[l] = cells;
         cells += nc * nr;
-        a.tile_base[l] = tiles, a.tiles_x[l] = ORBX_FAST_TILES_X(w);
-        tiles += a.tiles_x[l] * ORBX_FAST_TILES_Y(h);
+        a.tile_base[l] = tiles;
+        for (int ty = 0; ty < ORBX_FAST_TILES_Y(h); ty++)
+            for (int tx = 0; tx < ORBX_FAST_TILES_X(w); tx++)
+                tile_tab.push_back(ORBX_TILE_ENTRY(l, ty, tx));
+        tiles = (int)tile_tab.size();
         a.cand_base[l] = cand, a.cand_cap[l] = align_up(w * h / 4 + 4, 4);
         cand += a.cand_cap[l];
         a.wc_magic[l] = ((1u << 20) + a.wcell[l] - 1) / a.wcell[l];
@@ -87,6 +91,9 @@ int main(int argc, char **argv)
     CK(hipMalloc(&d_flag, (size_t)B * cells));
     CK(hipMalloc(&d_cnt, (size_t)B * tiles * 4));
     CK(hipMalloc(&d_list, (size_t)B * tiles * ORBX_TILE_CAP * 8));
+    uint32_t *d_tab;
+    CK(hipMalloc(&d_tab, tile_tab.size() * 4));
+    CK(hipMemcpy(d_tab, tile_tab.data(), tile_tab.size() * 4, hipMemcpyHostToDevice));
     std::vector<uint8_t> slab((size_t)a.slab);
     std::vector<std::vector<uint8_t>> imgs(8, std::vector<uint8_t>((size_t)W * H));
     for (int f0 = 0; f0 < B; f0 += 8) {
@@ -114,10 +121,10 @@ int main(int argc, char **argv)
     for (int cut = 0; cut <= 4; cut++) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_cut), &cut, 4));
         for (int r = 0; r < 3; r++)
-            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_list, d_flag, a);
+            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_list, d_flag, d_tab, a);
         CK(hipEventRecord(e0, 0));
         for (int r = 0; r < reps; r++)
-            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_list, d_flag, a);
+            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_list, d_flag, d_tab, a);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(&t[cut], e0, e1));

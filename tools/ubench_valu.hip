@@ -77,6 +77,10 @@
 #define I_XOR3(R) "v_xor3_b32 " R ", " R ", %8, %9"
 #define I_OR3(R) "v_or3_b32 " R ", " R ", %8, %9"
 #define I_LSHLADD(R) "v_lshl_add_u32 " R ", " R ", 3, %8"
+#define I_AND_LIT(R) "v_and_b32 " R ", 0x7f7f7f7f, " R
+#define I_AND_INL(R) "v_and_b32 " R ", 15, " R
+#define I_ADD_S(R) "v_add_u32 " R ", %10, " R
+#define I_SUB_LIT(R) "v_sub_u32 " R ", 0x80808080, " R
 #define I_CNDMASK_S(R) "v_cndmask_b32 " R ", " R ", %8, s[10:11]"
 #define I_CMP(R) "v_cmp_lt_u32 vcc, " R ", %8"
 #define I_PKLSHL(R) "v_pk_lshlrev_b16 " R ", 1, " R
@@ -160,6 +164,10 @@ KERNEL(add3_u32, I_ADD3)
 KERNEL(or3_b32, I_OR3)
 KERNEL(lshl_add_u32, I_LSHLADD)
 KERNEL(cndmask_sgpr, I_CNDMASK_S)
+KERNEL(and_b32_literal, I_AND_LIT)
+KERNEL(and_b32_inline, I_AND_INL)
+KERNEL(add_u32_sgpr, I_ADD_S)
+KERNEL(sub_u32_literal, I_SUB_LIT)
 KERNEL(cmp_lt_u32, I_CMP)
 KERNEL(pk_lshlrev_b16, I_PKLSHL)
 KERNEL(bfi_b32, I_BFI)
@@ -188,6 +196,46 @@ KERNEL_MIX(mix_1add_1pkmax, ROUND(I_ADD) ROUND(I_PKMAX) ROUND(I_ADD) ROUND(I_PKM
 KERNEL_MIX(mix_3add_1pkmax, ROUND(I_ADD) ROUND(I_XOR) ROUND(I_SUB) ROUND(I_PKMAX) ROUND(I_ADD) ROUND(I_XOR) ROUND(I_SUB) ROUND(I_PKMAX))
 KERNEL_MIX(mix_1and_1perm, ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM))
 
+
+// Scalar instructions: eight independent scalar chains per wave (one scalar unit serves the four SIMDs of a
+// compute unit), alone and beside vector instructions of the same wave.
+#define SROUND(INS)                                                                                             \
+    asm volatile(INS("%0") "\n" INS("%1") "\n" INS("%2") "\n" INS("%3") "\n" INS("%4") "\n" INS("%5") "\n" INS("%6") \
+                     "\n" INS("%7")                                                                             \
+                 : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(q4), "+s"(q5), "+s"(q6), "+s"(q7)               \
+                 : "s"(sc));
+#define S_ADD(R) "s_add_u32 " R ", " R ", %8"
+#define S_AND(R) "s_and_b32 " R ", " R ", %8"
+#define S_MUL(R) "s_mul_i32 " R ", " R ", %8"
+#define S_WAIT(R) "s_waitcnt lgkmcnt(0)"
+#define S_NOP(R) "s_nop 0"
+#define KERNEL_SMIX(NAME, SEQ)                                                                         \
+    __global__ __launch_bounds__(256) void k_##NAME(uint32_t *out, long long *clk, uint32_t seed, int iters) \
+    {                                                                                                  \
+        uint32_t r0 = seed + threadIdx.x, r1 = r0 * 3u, r2 = r0 * 5u, r3 = r0 * 7u, r4 = r0 * 11u, r5 = r0 * 13u, \
+                 r6 = r0 * 17u, r7 = r0 * 19u;                                                         \
+        uint32_t q0 = seed, q1 = seed * 3u, q2 = seed * 5u, q3 = seed * 7u, q4 = seed * 11u, q5 = seed * 13u,  \
+                 q6 = seed * 17u, q7 = seed * 19u;                                                     \
+        const uint32_t x = seed * 0x9E3779B9u + threadIdx.x, y = 0x07050301u ^ (seed & 0x03030303u);   \
+        const uint32_t sc = seed * 77u;                                                                \
+        const long long t0 = __builtin_amdgcn_s_memtime();                                             \
+        for (int it = 0; it < iters; it++) {                                                           \
+            SEQ                                                                                        \
+        }                                                                                              \
+        const long long t1 = __builtin_amdgcn_s_memtime();                                             \
+        out[blockIdx.x * 256 + threadIdx.x] =                                                          \
+            r0 ^ r1 ^ r2 ^ r3 ^ r4 ^ r5 ^ r6 ^ r7 ^ q0 ^ q1 ^ q2 ^ q3 ^ q4 ^ q5 ^ q6 ^ q7;              \
+        if ((threadIdx.x & 63) == 0)                                                                   \
+            clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                        \
+    }
+KERNEL_SMIX(s_add_u32, SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD))
+KERNEL_SMIX(s_mul_i32, SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL))
+KERNEL_SMIX(s_waitcnt, SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT))
+KERNEL_SMIX(s_nop, SROUND(S_NOP) SROUND(S_NOP) SROUND(S_NOP) SROUND(S_NOP) SROUND(S_NOP) SROUND(S_NOP) SROUND(S_NOP) SROUND(S_NOP))
+// per_op 1: the rate printed counts the vector instructions only (32 per iteration beside 32 scalar ones)
+KERNEL_SMIX(mix_1sadd_1pkmax, ROUND(I_PKMAX) SROUND(S_ADD) ROUND(I_PKMAX) SROUND(S_ADD) ROUND(I_PKMAX) SROUND(S_ADD) ROUND(I_PKMAX) SROUND(S_ADD))
+KERNEL_SMIX(mix_1sadd_1add, ROUND(I_ADD) SROUND(S_ADD) ROUND(I_ADD) SROUND(S_ADD) ROUND(I_ADD) SROUND(S_ADD) ROUND(I_ADD) SROUND(S_ADD))
+
 typedef void (*kern_t)(uint32_t *, long long *, uint32_t, int);
 struct Entry {
     const char *name;
@@ -201,8 +249,9 @@ static const Entry entries[] = {E(fma_f32),      E(add_u32),      E(xor_b32),   
                                 E(mul_lo_u32),   E(dot4_u32_u8),  E(dot2_u32_u16), E(max3_u32),     E(med3_i32),
                                 E(min_u32),      E(and_or_b32),   E(lshl_or_b32),  E(cndmask_b32),  E(sad_u8),
                                 E(msad_u8),      E(bfe_u32),
-    E(and_b32), E(or_b32), E(sub_u32), E(subrev_u32), E(lshlrev_b32), E(lshrrev_b32), E(max_f32), E(min_f32), E(mul_f32), E(add_f32), E(max_u32), E(max_i32), E(pk_max_f16), E(pk_min_f16), E(pk_add_f16), E(pk_fma_f16), E(pk_max_i16), E(max_f16), E(max_u16), E(add_u16), E(cvt_f32_ubyte0), E(mov_b32), E(max3_f32), E(min3_f32), E(med3_f32), E(add3_u32), E(or3_b32), E(lshl_add_u32), E(cndmask_sgpr), E(cmp_lt_u32), E(pk_lshlrev_b16), E(bfi_b32), E(alignbit_b32), E(max_u16_sdwa), E(add_u32_sdwa),
-    E(mix_1add_1pkmax), E(mix_3add_1pkmax), E(mix_1and_1perm)};
+    E(and_b32), E(or_b32), E(sub_u32), E(subrev_u32), E(lshlrev_b32), E(lshrrev_b32), E(max_f32), E(min_f32), E(mul_f32), E(add_f32), E(max_u32), E(max_i32), E(pk_max_f16), E(pk_min_f16), E(pk_add_f16), E(pk_fma_f16), E(pk_max_i16), E(max_f16), E(max_u16), E(add_u16), E(cvt_f32_ubyte0), E(mov_b32), E(max3_f32), E(min3_f32), E(med3_f32), E(add3_u32), E(or3_b32), E(lshl_add_u32), E(cndmask_sgpr), E(and_b32_literal), E(and_b32_inline), E(add_u32_sgpr), E(sub_u32_literal), E(cmp_lt_u32), E(pk_lshlrev_b16), E(bfi_b32), E(alignbit_b32), E(max_u16_sdwa), E(add_u32_sdwa),
+    E(mix_1add_1pkmax), E(mix_3add_1pkmax), E(mix_1and_1perm),
+    E(s_add_u32), E(s_mul_i32), E(s_waitcnt), E(s_nop), E(mix_1sadd_1pkmax), E(mix_1sadd_1add)};
 
 int main(int argc, char **argv)
 {
