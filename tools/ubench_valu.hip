@@ -203,7 +203,8 @@ KERNEL_MIX(mix_1and_1perm, ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM)
     asm volatile(INS("%0") "\n" INS("%1") "\n" INS("%2") "\n" INS("%3") "\n" INS("%4") "\n" INS("%5") "\n" INS("%6") \
                      "\n" INS("%7")                                                                             \
                  : "+s"(q0), "+s"(q1), "+s"(q2), "+s"(q3), "+s"(q4), "+s"(q5), "+s"(q6), "+s"(q7)               \
-                 : "s"(sc));
+                 : "s"(sc)                                                                                     \
+                 : "s20", "s21", "scc");
 #define S_ADD(R) "s_add_u32 " R ", " R ", %8"
 #define S_AND(R) "s_and_b32 " R ", " R ", %8"
 #define S_MUL(R) "s_mul_i32 " R ", " R ", %8"
@@ -228,6 +229,13 @@ KERNEL_MIX(mix_1and_1perm, ROUND(I_AND) ROUND(I_PERM) ROUND(I_AND) ROUND(I_PERM)
         if ((threadIdx.x & 63) == 0)                                                                   \
             clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;                                        \
     }
+#define S_MOV(R) "s_mov_b32 " R ", 0x12345678"
+#define S_SAVEEXEC(R) "s_and_saveexec_b64 s[20:21], vcc\n s_or_b64 exec, exec, s[20:21]"
+#define S_CMPSEL(R) "s_cmp_lt_u32 " R ", %8\n s_cselect_b32 " R ", " R ", %8"
+KERNEL_SMIX(s_mov_b32, SROUND(S_MOV) SROUND(S_MOV) SROUND(S_MOV) SROUND(S_MOV) SROUND(S_MOV) SROUND(S_MOV) SROUND(S_MOV) SROUND(S_MOV))
+// two instructions per expansion: the rate printed counts expansions
+KERNEL_SMIX(s_saveexec_or, SROUND(S_SAVEEXEC) SROUND(S_SAVEEXEC) SROUND(S_SAVEEXEC) SROUND(S_SAVEEXEC) SROUND(S_SAVEEXEC) SROUND(S_SAVEEXEC) SROUND(S_SAVEEXEC) SROUND(S_SAVEEXEC))
+KERNEL_SMIX(s_cmp_cselect, SROUND(S_CMPSEL) SROUND(S_CMPSEL) SROUND(S_CMPSEL) SROUND(S_CMPSEL) SROUND(S_CMPSEL) SROUND(S_CMPSEL) SROUND(S_CMPSEL) SROUND(S_CMPSEL))
 KERNEL_SMIX(s_add_u32, SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD) SROUND(S_ADD))
 KERNEL_SMIX(s_mul_i32, SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL) SROUND(S_MUL))
 KERNEL_SMIX(s_waitcnt, SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT) SROUND(S_WAIT))
@@ -251,7 +259,7 @@ static const Entry entries[] = {E(fma_f32),      E(add_u32),      E(xor_b32),   
                                 E(msad_u8),      E(bfe_u32),
     E(and_b32), E(or_b32), E(sub_u32), E(subrev_u32), E(lshlrev_b32), E(lshrrev_b32), E(max_f32), E(min_f32), E(mul_f32), E(add_f32), E(max_u32), E(max_i32), E(pk_max_f16), E(pk_min_f16), E(pk_add_f16), E(pk_fma_f16), E(pk_max_i16), E(max_f16), E(max_u16), E(add_u16), E(cvt_f32_ubyte0), E(mov_b32), E(max3_f32), E(min3_f32), E(med3_f32), E(add3_u32), E(or3_b32), E(lshl_add_u32), E(cndmask_sgpr), E(and_b32_literal), E(and_b32_inline), E(add_u32_sgpr), E(sub_u32_literal), E(cmp_lt_u32), E(pk_lshlrev_b16), E(bfi_b32), E(alignbit_b32), E(max_u16_sdwa), E(add_u32_sdwa),
     E(mix_1add_1pkmax), E(mix_3add_1pkmax), E(mix_1and_1perm),
-    E(s_add_u32), E(s_mul_i32), E(s_waitcnt), E(s_nop), E(mix_1sadd_1pkmax), E(mix_1sadd_1add)};
+    E(s_add_u32), E(s_mov_b32), E(s_saveexec_or), E(s_cmp_cselect), E(s_mul_i32), E(s_waitcnt), E(s_nop), E(mix_1sadd_1pkmax), E(mix_1sadd_1add)};
 
 int main(int argc, char **argv)
 {
