@@ -531,7 +531,7 @@ template <int NT, int KMAX, typename... Args> __device__ __forceinline__ void oc
 }
 
 template <int NT, int KMAX>
-__global__ __launch_bounds__(NT) void k_octree(const uint32_t *__restrict__ cand_xy,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_octree(const uint32_t *__restrict__ cand_xy,
                                                 const uint8_t *__restrict__ cand_resp,
                                                 const uint32_t *__restrict__ cand_key,
                                                 const uint8_t *__restrict__ cell_ini, uint16_t *__restrict__ cand_node,
