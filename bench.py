@@ -258,6 +258,8 @@ def main():
         roofline["valu_issue_ceilings_T_wave_instr_per_s"] = {
             "packed_16bit_perm_mad_dot_3input": VALU_WAVE_INSTR_PER_S_SLOW / 1e12,
             "add_sub_logic_f32": VALU_WAVE_INSTR_PER_S_FAST / 1e12,
+            # measured streams that alternate the two classes; the kernel's own mix lies between the two
+            "mix_1_fast_per_slow": 0.65, "mix_3_fast_per_slow": 0.77,
             "source": "tools/ubench_valu.hip, profiles/r02/ubench_valu.txt"}
         roofline["valu_frac_of_slow_class_ceiling"] = round(valu / dom_s / VALU_WAVE_INSTR_PER_S_SLOW, 4)
 
