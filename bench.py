@@ -52,9 +52,9 @@ MAC_PER_PAIR = 256
 
 WORKLOADS = {
     # name: (width, height, nfeatures, frames per batch)
-    # 512 frames per step = 128 per launch of each of the four instances (64 per launch: 3 % fewer frames/s,
-    # 256 per launch: 1 % more)
-    "kitti_1241x376_2000kp": (1241, 376, 2000, 512),
+    # 1024 frames per step = 256 per launch of each of the four instances (128 per launch: 2 % fewer frames/s,
+    # 64 per launch: 5 % fewer)
+    "kitti_1241x376_2000kp": (1241, 376, 2000, 1024),
     "euroc_752x480_1000kp": (752, 480, 1000, 128),
     "tum_640x480_1000kp": (640, 480, 1000, 128),
 }
@@ -100,7 +100,7 @@ def main():
                     help="one instance, stages serialised and profiled inside the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hamming", action="store_true")
-    ap.add_argument("--frames-resident", type=int, default=1024,
+    ap.add_argument("--frames-resident", type=int, default=2048,
                     help="synthetic frames resident in HBM per GPU; the steps rotate through them (default: a set larger "
                          "than the 256 MiB Infinity Cache, so that level 0 cannot stay cached between steps)")
     ap.add_argument("--no-config5", action="store_true")
