@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
                                                       float *__restrict__ depth, int *__restrict__ sad, StereoArgs a)
 {
     __shared__ int part[4][11][12];  // per wave: window distance of (shift, row)
+    __shared__ uint32_t win[4][11][10];  // per wave: rows of the left window (4 words) and the right strip (6 words)
     __shared__ float s_rad[ORBX_MAX_LEVELS];  // 2 * scale factor of a level: the row radius of a right keypoint
     const int f = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < ORBX_MAX_LEVELS)
@@ -148,16 +149,38 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
                                                 : pyrR + (size_t)f * a.slabR + a.off[levelL];
                 const int pL = levelL == 0 ? a.l0L.pitch : a.pitch[levelL];
                 const int pR = levelL == 0 ? a.l0R.pitch : a.pitch[levelL];
-                const int cL = IL[(size_t)sv * pL + su];
+                // The 11 x 11 window of the left level and the 11 x 21 strip of the right one, as aligned words
+                // (4 and 6 to a row: 110 words, two loads of the wave) through LDS; the 121 window distances
+                // then read bytes from there.  (44 byte loads per lane straight from global memory kept the
+                // address unit busy for half of the kernel's time.)  The words may reach 3 bytes past the
+                // window, which stays inside the row or, at most, in the first bytes of the next one.
+                const int xl = (su - w) & ~3, xr = (sr - L - w) & ~3;
+                const int oL = (su - w) - xl, oR = (sr - L - w) - xr;
+                uint32_t *ws = &win[wv][0][0];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int i = lane + 64 * k;
+                    if (i < 11 * 10) {
+                        const int r = i / 10, j = i - r * 10;
+                        const uint8_t *src = j < 4 ? IL + (size_t)(sv + r - w) * pL + xl + 4 * j
+                                                   : IR + (size_t)(sv + r - w) * pR + xr + 4 * (j - 4);
+                        ws[i] = *reinterpret_cast<const uint32_t *>(src);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const uint8_t *wb = reinterpret_cast<const uint8_t *>(ws);  // row r: 16 left bytes, 24 right bytes
+                const int cL = wb[w * 40 + oL + w];
                 // 121 (shift, row) items over the 64 lanes
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const int item = lane + 64 * k;
                     if (item < 121) {
                         const int s = item / 11, r = item - s * 11;  // incR = s - 5, window row r - 5
-                        const int cR = IR[(size_t)sv * pR + sr + s - L];
-                        const uint8_t *lp = IL + (size_t)(sv + r - w) * pL + su - w;
-                        const uint8_t *rp = IR + (size_t)(sv + r - w) * pR + sr + s - L - w;
+                        const int cR = wb[w * 40 + 16 + oR + s + w];
+                        const uint8_t *lp = wb + r * 40 + oL;
+                        const uint8_t *rp = wb + r * 40 + 16 + oR + s;
                         int acc = 0;
 #pragma unroll
                         for (int x = 0; x < 11; x++)
