@@ -67,7 +67,7 @@ struct orbx_extractor {
     OrbxBuffers buf;
     // stereo matching workspace (allocated on first use) and the batch pair it holds results for
     int *st_rowstart;
-    uint16_t *st_sorted;
+    uint4 *st_sorted;  // right keypoints in row order: a 16-byte record each, then their descriptors
     int *st_sad, *st_nmatch;
     float *st_uright, *st_depth;
     hipEvent_t ev_stereo;
@@ -1536,7 +1536,7 @@ extern "C" int orbx_compute_stereo_matches_device(orbx_extractor *left, orbx_ext
         if (!left->st_rowstart)
             HIP_TRY(hipMalloc((void **)&left->st_rowstart, B * (size_t)(left->p.max_height + 1) * sizeof(int)));
         if (!left->st_sorted)
-            HIP_TRY(hipMalloc((void **)&left->st_sorted, B * (size_t)c.out_cap * sizeof(uint16_t)));
+            HIP_TRY(hipMalloc((void **)&left->st_sorted, B * (size_t)c.out_cap * 3 * sizeof(uint4)));
         if (!left->st_sad)
             HIP_TRY(hipMalloc((void **)&left->st_sad, B * (size_t)c.out_cap * sizeof(int)));
         if (!left->ev_stereo)

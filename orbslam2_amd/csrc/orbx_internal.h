@@ -184,7 +184,7 @@ hipError_t orbx_launch_top2(const uint8_t *d_q, int nq, const uint8_t *d_db, int
                             uint32_t *d_partial, int chunk_rows, int nchunks, int32_t *d_best, uint16_t *d_d1,
                             uint16_t *d_d2, hipStream_t s);
 hipError_t orbx_launch_stereo(const OrbxGeom &g, const OrbxBuffers &bl, const OrbxBuffers &br, const float *sf,
-                              const float *inv, float mb, float mbf, int *d_rowstart, uint16_t *d_sorted, int *d_sad,
+                              const float *inv, float mb, float mbf, int *d_rowstart, uint4 *d_sorted, int *d_sad,
                               float *d_uright, float *d_depth, int *d_nmatch, hipStream_t s);
 hipError_t orbx_launch_distinctive(const uint8_t *d_desc, const int *d_seg_start, int npoints, int32_t *d_best_idx,
                                    uint8_t *d_best_desc, hipStream_t s);

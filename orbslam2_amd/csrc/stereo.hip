@@ -22,9 +22,10 @@ struct StereoArgs {
 };
 
 // ---- right keypoints bucketed by floor(y): rowstart[f][0..h0], sorted[f][...] (any order inside a row) ----
-__global__ __launch_bounds__(256) void k_stereo_rows(const orbx_keypoint *__restrict__ kpR, const int *__restrict__ nR,
-                                                     int *__restrict__ rowstart, uint16_t *__restrict__ sorted,
-                                                     int out_cap, int h0)
+__global__ __launch_bounds__(256) void k_stereo_rows(const orbx_keypoint *__restrict__ kpR,
+                                                     const uint8_t *__restrict__ dR, const int *__restrict__ nR,
+                                                     int *__restrict__ rowstart, uint4 *__restrict__ sorted,
+                                                     int out_cap, int h0, StereoArgs a)
 {
     extern __shared__ int hist[];  // h0 + 1 counters, then their exclusive prefix
     __shared__ int wsum[4];
@@ -66,10 +67,21 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const orbx_keypoint *__rest
         base += c;
     }
     __syncthreads();
-    uint16_t *so = sorted + (size_t)f * out_cap;
+    // In bucket order: what the matcher tests of a right keypoint (x, the rows it is listed in, its level, its
+    // index) as one 16-byte record, and its descriptor behind it.  The lanes of a matcher wave then read
+    // neighbouring records instead of gathering fields of keypoints scattered over the frame's arrays.
+    uint4 *rec = sorted + (size_t)f * out_cap * 3;
+    const uint4 *dsrc = reinterpret_cast<const uint4 *>(dR) + (size_t)f * out_cap * 2;
     for (int i = tid; i < n; i += 256) {
-        const int iy = min(max((int)floorf(k[i].y), 0), h0 - 1);
-        so[atomicAdd(&hist[iy], 1)] = (uint16_t)i;
+        const orbx_keypoint r = k[i];
+        const int iy = min(max((int)floorf(r.y), 0), h0 - 1);
+        const int p = atomicAdd(&hist[iy], 1);
+        const float rad = 2.0f * a.sf[r.octave];
+        const int maxr = (int)ceilf(r.y + rad), minr = (int)floorf(r.y - rad);
+        rec[p] = make_uint4(__float_as_uint(r.x), ((uint32_t)minr & 0xffffu) | ((uint32_t)maxr << 16),
+                            (uint32_t)r.octave | ((uint32_t)i << 16), 0u);
+        rec[out_cap + 2 * p] = dsrc[2 * i];
+        rec[out_cap + 2 * p + 1] = dsrc[2 * i + 1];
     }
 }
 
@@ -79,16 +91,12 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
                                                       const uint8_t *__restrict__ dR, const int *__restrict__ nR,
                                                       const uint8_t *__restrict__ pyrL, const uint8_t *__restrict__ pyrR,
                                                       const int *__restrict__ rowstart,
-                                                      const uint16_t *__restrict__ sorted, float *__restrict__ uright,
+                                                      const uint4 *__restrict__ sorted, float *__restrict__ uright,
                                                       float *__restrict__ depth, int *__restrict__ sad, StereoArgs a)
 {
     __shared__ int part[4][11][12];  // per wave: window distance of (shift, row)
     __shared__ uint32_t win[4][11][10];  // per wave: rows of the left window (4 words) and the right strip (6 words)
-    __shared__ float s_rad[ORBX_MAX_LEVELS];  // 2 * scale factor of a level: the row radius of a right keypoint
     const int f = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x < ORBX_MAX_LEVELS)
-        s_rad[threadIdx.x] = threadIdx.x < (unsigned)a.nlevels ? 2.0f * a.sf[threadIdx.x] : 0.f;
-    __syncthreads();
     const int iL = blockIdx.x * 4 + wv;
     if (iL >= a.out_cap)
         return;
@@ -104,38 +112,42 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint *__res
         const float minZ = a.mb, minD = 0.0f, maxD = a.mbf / minZ;
         const float minU = uL - maxD, maxU = uL - minD;
         uint32_t best = 0xffffffffu;
+        float best_x = 0.f;  // x of this lane's best candidate
         if (row >= 0 && row < h0 && !(maxU < 0)) {
             const int *rs = rowstart + (size_t)f * (h0 + 1);
             const int c_lo = rs[max(row - a.band, 0)], c_hi = rs[min(row + a.band + 1, h0)];
-            const uint16_t *so = sorted + (size_t)f * a.out_cap;
-            const orbx_keypoint *kr = kpR + (size_t)f * a.out_cap;
+            const uint4 *rec = sorted + (size_t)f * a.out_cap * 3;
             const uint32_t *q = reinterpret_cast<const uint32_t *>(dL) + o * 8;
             uint32_t qd[8];
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 qd[k] = q[k];
             for (int c = c_lo + lane; c < c_hi; c += 64) {
-                const int iR = so[c];
-                const orbx_keypoint r = kr[iR];
-                const float rad = s_rad[r.octave];
-                const int maxr = (int)ceilf(r.y + rad), minr = (int)floorf(r.y - rad);
-                if (row < minr || row > maxr || r.octave < levelL - 1 || r.octave > levelL + 1)
+                const uint4 r = rec[c];  // x | rows it is listed in | level, index
+                const int minr = (int)(short)(r.y & 0xffffu), maxr = (int)(r.y >> 16);
+                const int oct = (int)(r.z & 0xffffu);
+                if (row < minr || row > maxr || oct < levelL - 1 || oct > levelL + 1)
                     continue;
-                if (r.x >= minU && r.x <= maxU) {
-                    const uint32_t *rd = reinterpret_cast<const uint32_t *>(dR) + ((size_t)f * a.out_cap + iR) * 8;
-                    uint32_t d = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        d += __popc(qd[k] ^ rd[k]);
-                    best = min(best, (d << 16) | (uint32_t)iR);
+                const float rx = __uint_as_float(r.x);
+                if (rx >= minU && rx <= maxU) {
+                    const uint4 d0 = rec[a.out_cap + 2 * c], d1 = rec[a.out_cap + 2 * c + 1];
+                    const uint32_t d = __popc(qd[0] ^ d0.x) + __popc(qd[1] ^ d0.y) + __popc(qd[2] ^ d0.z) +
+                                       __popc(qd[3] ^ d0.w) + __popc(qd[4] ^ d1.x) + __popc(qd[5] ^ d1.y) +
+                                       __popc(qd[6] ^ d1.z) + __popc(qd[7] ^ d1.w);
+                    const uint32_t key = (d << 16) | (r.z >> 16);
+                    if (key < best)
+                        best = key, best_x = rx;
                 }
             }
         }
+        const uint32_t mine = best;
         best = orbx_wave_min_u32(best);
         // bestDist starts at TH_HIGH and must end below (TH_HIGH + TH_LOW) / 2 (:590, :620)
         if (best != 0xffffffffu && (int)(best >> 16) < a.th_orb) {
-            const int iR = best & 0xffffu;
-            const float uR0 = kpR[(size_t)f * a.out_cap + iR].x;
+            // x of the winner from the lane that holds it (keys are distinct: they end in the keypoint's index)
+            const unsigned long long owner = __ballot(mine == best);
+            const float uR0 = __builtin_bit_cast(
+                float, __builtin_amdgcn_readlane(__float_as_int(best_x), (int)__builtin_ctzll(owner)));
             const float scaleFactor = a.inv[levelL];
             const float scaleduL = roundf(kl.x * scaleFactor), scaledvL = roundf(kl.y * scaleFactor);
             const float scaleduR0 = roundf(uR0 * scaleFactor);
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int *__restrict__ n
 }
 
 hipError_t orbx_launch_stereo(const OrbxGeom &g, const OrbxBuffers &bl, const OrbxBuffers &br, const float *sf,
-                              const float *inv, float mb, float mbf, int *d_rowstart, uint16_t *d_sorted, int *d_sad,
+                              const float *inv, float mb, float mbf, int *d_rowstart, uint4 *d_sorted, int *d_sad,
                               float *d_uright, float *d_depth, int *d_nmatch, hipStream_t s)
 {
     StereoArgs a;
@@ -329,8 +341,8 @@ hipError_t orbx_launch_stereo(const OrbxGeom &g, const OrbxBuffers &bl, const Or
     a.band = (int)ceilf(rmax) + 1;  // |floor(yR) - row| of any listed right keypoint stays within this
     a.mb = mb, a.mbf = mbf;
     const int h0 = g.lv[0].h;
-    k_stereo_rows<<<g.batch, 256, (size_t)(h0 + 1) * sizeof(int), s>>>(br.out_kp, br.out_n, d_rowstart, d_sorted,
-                                                                       g.out_cap, h0);
+    k_stereo_rows<<<g.batch, 256, (size_t)(h0 + 1) * sizeof(int), s>>>(br.out_kp, br.out_desc, br.out_n, d_rowstart,
+                                                                       d_sorted, g.out_cap, h0, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
