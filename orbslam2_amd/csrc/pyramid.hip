@@ -104,33 +104,46 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
         }
     };
 
-    // Source rows first_row .. last_row in turn, the next one loading while this one is filtered.  A
-    // destination row reads source rows (j - 1, j), or (j, j) where the table clamps at the last row, and
-    // is written when row j has been filtered.
-    const int first_row = yt[dy0].sy0;
-    uint32_t ahead[3] = {0, 0, 0}, prev[4] = {0, 0, 0, 0};
-    load_row(first_row, ahead);
-    int dy = dy0;
-    OrbxYCoef c = yt[dy];
-    for (int j = first_row; j <= (int)last_row; j++) {
-        const uint32_t raw[3] = {ahead[0], ahead[1], ahead[2]};
-        if (j < (int)last_row)
-            load_row(j + 1, ahead);
-        uint32_t cur[4];
-        hpass(j, raw, cur);
-        while (dy < dy1 && c.sy1 == j) {
-            // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 for four pixels: the upper halves
-            // of the eight products are gathered two pixels to a register and added, rounded and shifted as
-            // packed 16-bit values (both products stay below 2^27, so 24-bit multiplies are exact)
-            if (c.sy0 == j) {
+    // The wave's row coefficients, all at once (its rows are uniform: scalar loads), so that the loop below
+    // holds no load of them and no wait.  Entries past dy1 repeat the last row's.
+    OrbxYCoef C[RS_ROWS];
+#pragma unroll
+    for (int d = 0; d < RS_ROWS; d++)
+        C[d] = yt[__builtin_amdgcn_readfirstlane(min(dy0 + d, dy1 - 1))];
+    // Destination rows in turn; `cur` holds the horizontal pass of source row j, `prev` that of row j - 1, and the
+    // row after j is loading.  A destination row reads source rows (sy1 - 1, sy1), or (sy1, sy1) where the table
+    // clamps at the border; j advances to sy1 by one step mostly, by two where the ratio skips a source row.
+    int j = C[0].sy0;
+    uint32_t ahead[3] = {0, 0, 0}, raw[3], prev[4], cur[4];
+    load_row(j, raw);
+    if (j < (int)last_row)
+        load_row(j + 1, ahead);
+    hpass(j, raw, cur);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        prev[i] = cur[i];
+#pragma unroll
+    for (int d = 0; d < RS_ROWS; d++) {
+        if (dy0 + d < dy1) {
+            const OrbxYCoef c = C[d];
+            while (j < c.sy1) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     prev[i] = cur[i];
+                raw[0] = ahead[0], raw[1] = ahead[1], raw[2] = ahead[2];
+                j++;
+                if (j < (int)last_row)
+                    load_row(j + 1, ahead);
+                hpass(j, raw, cur);
             }
+            // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 for four pixels: the upper halves
+            // of the eight products are gathered two pixels to a register and added, rounded and shifted as
+            // packed 16-bit values (both products stay below 2^27, so 24-bit multiplies are exact)
+            const bool same = c.sy0 == c.sy1;
             uint32_t p0[4], p1[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                p0[i] = __umul24((uint32_t)c.b0, prev[i] >> 4);
+                p0[i] = __umul24((uint32_t)c.b0, (same ? cur[i] : prev[i]) >> 4);
                 p1[i] = __umul24((uint32_t)c.b1, cur[i] >> 4);
             }
             typedef unsigned short rs_pk __attribute__((ext_vector_type(2)));
@@ -140,13 +153,8 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
                 const rs_pk sum = __builtin_bit_cast(rs_pk, t) + __builtin_bit_cast(rs_pk, u) + (rs_pk){2, 2};
                 return __builtin_bit_cast(uint32_t, (rs_pk)(sum >> (rs_pk){2, 2}));
             };
-            put(dy, __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u));  // the four low bytes
-            if (++dy < dy1)
-                c = yt[__builtin_amdgcn_readfirstlane(dy)];  // the row is the wave's: a scalar load
+            put(dy0 + d, __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u));  // the four low bytes
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            prev[i] = cur[i];
     }
 }
 
