@@ -74,8 +74,9 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
     for (int i = 0; i < 4; i++)
         sel[i] = (uint32_t)(sx[i] - sx[0]) * 0x00010001u + 0x0c010c00u;  // bytes d, 0, d+1, 0
 
-    // horizontal pass of one source row, S[sx] * a0 + S[sx + 1] * a1 for the lane's four pixels, from the
-    // three words `w` loaded ahead (narrow lanes) or from single bytes
+    // horizontal pass of one source row, (S[sx] * a0 + S[sx + 1] * a1) >> 4 for the lane's four pixels (the shift
+    // is the vertical pass's, applied once per source row here), from the three words `w` loaded ahead (narrow
+    // lanes) or from single bytes
     const uint32_t wb_safe = narrow ? wb : 0u;  // other lanes load the words at the row's start and ignore them
     auto load_row = [&](int srow, uint32_t (&w)[3]) {
         const uint32_t *row =
@@ -90,7 +91,7 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
             for (int i = 0; i < 4; i++) {
                 const uint32_t pq = __builtin_amdgcn_perm(hi, lo, sel[i]);
                 o[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(rs_us2, pq), __builtin_bit_cast(rs_us2, coef[i]), 0u,
-                                              false);
+                                              false) >> 4;
             }
         } else {
             const uint8_t *row = sbase + __umul24((uint32_t)srow, (uint32_t)spitch);
@@ -99,7 +100,7 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
                 // a1 == 0 marks columns whose right neighbour must not be read
                 const uint32_t a0 = coef[i] & 0xffffu, a1 = coef[i] >> 16;
                 const int s1 = a1 ? sx[i] + 1 : sx[i];
-                o[i] = row[sx[i]] * a0 + row[s1] * a1;
+                o[i] = (row[sx[i]] * a0 + row[s1] * a1) >> 4;
             }
         }
     };
@@ -139,12 +140,17 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
             // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 for four pixels: the upper halves
             // of the eight products are gathered two pixels to a register and added, rounded and shifted as
             // packed 16-bit values (both products stay below 2^27, so 24-bit multiplies are exact)
-            const bool same = c.sy0 == c.sy1;
+            if (c.sy0 == c.sy1) {  // the wave's rows: a branch, taken at the border only
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    prev[i] = cur[i];
+            }
             uint32_t p0[4], p1[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                p0[i] = __umul24((uint32_t)c.b0, (same ? cur[i] : prev[i]) >> 4);
-                p1[i] = __umul24((uint32_t)c.b1, cur[i] >> 4);
+                p0[i] = __umul24((uint32_t)c.b0, prev[i]);
+                p1[i] = __umul24((uint32_t)c.b1, cur[i]);
             }
             typedef unsigned short rs_pk __attribute__((ext_vector_type(2)));
             auto pair = [&](int i) -> uint32_t {
