@@ -8,9 +8,9 @@
 // ---------------------------------------------------------------- blur
 
 struct BlurArgs {
-    int nlevels, slab, variant, batch;
+    int nlevels, slab, bslab, variant, batch;
     OrbxLevel0 l0;
-    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS];
+    int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], boff[ORBX_MAX_LEVELS];
 };
 
 __device__ __forceinline__ int reflect101(int i, int n)
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
     const int spitch = lvl == 0 ? a.l0.pitch : pitch;
     const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
-    uint8_t *dst = blur + (size_t)f * a.slab + a.off[lvl];
+    uint8_t *dst = blur + (size_t)f * a.bslab + a.boff[lvl];  // tiled: ORBX_BLUR_ADDR
     const uint32_t k0 = 18, k1 = 34, k2 = VARIANT ? 49 : 48, k3 = VARIANT ? 55 : 56;
     // the seven taps k0 k1 k2 k3 k2 k1 k0 laid over bytes o+1 .. o+7 of three words, for o = 0 .. 3
     const uint32_t t0a = (k0 << 8) | (k1 << 16) | (k2 << 24), t0b = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
@@ -194,11 +194,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 #pragma unroll
         for (int j = 0; j < 5; j++)
             q[j] = *reinterpret_cast<const uint4 *>(&hs[(2 * rb + j) * BL_W + cg * 4]);
+        // the thread's 4 x 4 pixels are one 16-byte piece of the tiled level (a group of 4 pixels, its 4 rows);
+        // rows below the level fall into the padding tile rows
+        uint32_t out[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const int y = ty0 + 4 * rb + j;
-            if (y >= h)
-                break;
             const bool odd = j & 1;
             const int p0 = j >> 1;
             const uint32_t c01 = odd ? o01 : e01, c23 = odd ? o23 : e23, c45 = odd ? o45 : e45, c67 = odd ? o67 : e67;
@@ -216,19 +216,21 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             }
             const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);  // bytes: acc0.b2, acc1.b2
             const uint32_t hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);  // upper half: acc2.b2, acc3.b2
-            *reinterpret_cast<uint32_t *>(dst + (uint32_t)(__umul24(y, pitch) + x)) = lo | hi;
+            out[j] = lo | hi;
         }
+        const int y0 = ty0 + 4 * rb;
+        *reinterpret_cast<uint4 *>(dst + (uint32_t)ORBX_BLUR_ADDR(x, y0, pitch)) = make_uint4(out[0], out[1], out[2], out[3]);
     }
 }
 
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
 {
     BlurArgs a;
-    a.nlevels = g.nlevels, a.slab = g.slab, a.variant = g.blur_variant, a.batch = g.batch;
+    a.nlevels = g.nlevels, a.slab = g.slab, a.bslab = g.bslab, a.variant = g.blur_variant, a.batch = g.batch;
     a.l0 = b.l0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
-        a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off;
+        a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off, a.boff[l] = L.boff;
     }
     if (g.blur_variant)
         k_blur<1><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, b.tile_tab, a);
@@ -313,9 +315,10 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 struct DescArgs {
-    int nlevels, slab, kp_per_frame, out_cap, batch;
+    int nlevels, slab, bslab, kp_per_frame, out_cap, batch;
     OrbxLevel0 l0;
-    int pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], kp_base[ORBX_MAX_LEVELS], patch_size[ORBX_MAX_LEVELS];
+    int pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], boff[ORBX_MAX_LEVELS], kp_base[ORBX_MAX_LEVELS],
+        patch_size[ORBX_MAX_LEVELS];
     float scale[ORBX_MAX_LEVELS];
 };
 
@@ -329,9 +332,12 @@ struct DescArgs {
 #define DESC_SLOTS (4 * DESC_KPW)  // keypoint slots per workgroup
 #define PAT_ROWS 31    // orientation patch: rows y-15 .. y+15
 #define PAT_WORDS 12   // 48 fetched bytes per row from the aligned word at or below x-15 (36 are needed)
-#define BLP_ROWS 37    // descriptor window on the blurred level: rows y-18 .. y+18
-#define BLP_WORDS 12   // 48 staged bytes per row from the aligned word at or below x-18 (44 are needed)
-#define BLP_REGS 7     // window words per lane
+// Descriptor window on the blurred level (rows y-18 .. y+18, columns x-18 .. x+18): fetched as the 64 x 40-pixel
+// block of the tiled level that starts at the tile column of x-18 and the 4-row half tile of y-18, ten loads of
+// four whole 64-byte pieces each (lanes 16t .. 16t+15 take the piece of tile column t), and laid out in LDS as
+// rows of 64 bytes.
+#define BLP_PITCH 64   // bytes per window row in LDS
+#define BLP_REGS 10    // loads per window: one per half tile row
 #define BLP_SLOTS (64 * BLP_REGS)  // words of a wave's window buffer
 
 // One workgroup per DESC_SLOTS consecutive output slots of a frame, DESC_KPW keypoints per wave.  A
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     __shared__ uint32_t s_win[4 * BLP_SLOTS];  // a window per wave
     __shared__ uint32_t s_xy[DESC_SLOTS];                // level coordinates of the block's keypoints
     __shared__ int s_lvl[DESC_SLOTS], s_ki[DESC_SLOTS];  // their level and index into the kept arrays
-    __shared__ int s_pitch[DESC_SLOTS], s_off[DESC_SLOTS];  // row pitch and slab offset of that level (blurred image)
+    __shared__ int s_pitch[DESC_SLOTS], s_off[DESC_SLOTS];  // row pitch of that level and its offset in the blurred slab
     __shared__ int s_upitch[DESC_SLOTS];                    // row pitch of the unblurred level
     __shared__ long long s_usrc[DESC_SLOTS];                // byte offset of the unblurred level from pyr
     __shared__ float s_scale[DESC_SLOTS], s_size[DESC_SLOTS], s_resp[DESC_SLOTS];
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         s_lvl[threadIdx.x] = lvl;
         s_ki[threadIdx.x] = ki;
         s_pitch[threadIdx.x] = a.pitch[lvl];
-        s_off[threadIdx.x] = a.off[lvl];
+        s_off[threadIdx.x] = a.boff[lvl];
         s_upitch[threadIdx.x] = lvl == 0 ? a.l0.pitch : a.pitch[lvl];
         s_usrc[threadIdx.x] = lvl == 0 ? (long long)(a.l0.ptr - pyr) + (long long)f * a.l0.fstride
                                        : (long long)f * a.slab + a.off[lvl];
@@ -542,33 +548,32 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 #pragma unroll
     for (int j = 0; j < 4; j++)
         pat[j] = *reinterpret_cast<const float4 *>(&c_pattern_f.v[(lane + 64 * j) * 4]);
-    uint32_t brow[BLP_REGS], bcol[BLP_REGS];  // this lane's (row, byte column) of the window words it fetches
-#pragma unroll
-    for (int j = 0; j < BLP_REGS; j++) {
-        const uint32_t idx = lane + 64 * j;
-        const uint32_t q = __umul24(idx, 5462u) >> 16;  // idx / 12
-        const uint32_t r = q < BLP_ROWS ? q : BLP_ROWS - 1;  // slots 444 .. 447 read row 36 again
-        brow[j] = r, bcol[j] = 4 * (idx - __umul24(q, BLP_WORDS));
-    }
-    auto fetch_window = [&](int ls, uint32_t (&tmp)[BLP_REGS], uint32_t &ox) {
+    // this lane's bytes inside a 4-row strip of the block: tile column lane / 16, then the piece's own order
+    // (group of 4 pixels, row); in LDS the same word lies at row lane & 3, byte column 16 * (lane / 16) + 4 * group
+    const uint32_t lane_src = (uint32_t)(lane >> 4) * 128u + (uint32_t)(lane & 15) * 4u;
+    const uint32_t lane_dst = (uint32_t)(lane & 3) * (BLP_PITCH / 4) + (uint32_t)(lane >> 4) * 4u + (uint32_t)((lane & 15) >> 2);
+    auto fetch_window = [&](int ls, uint32_t (&tmp)[BLP_REGS], uint32_t &oxy) {
         const uint32_t xy = __builtin_amdgcn_readfirstlane(s_xy[ls]);
         const int x = xy & 0xffff, y = xy >> 16;
         const int pitch = __builtin_amdgcn_readfirstlane(s_pitch[ls]);
         const int off = __builtin_amdgcn_readfirstlane(s_off[ls]);
-        const int xa = (x - 18) & ~3;
-        ox = (uint32_t)((x - 18) - xa);
-        const uint8_t *src = blur + (size_t)f * a.slab + off + (long long)(y - 18) * pitch + xa;
+        const int ax = (x - 18) & ~15, ay = (y - 18) & ~3;
+        oxy = (uint32_t)((y - 18 - ay) * BLP_PITCH + (x - 18 - ax));  // the window's first pixel inside the block
+        const uint8_t *src = blur + (size_t)f * a.bslab + off + (ax >> 4) * 128;
+        const int hr0 = ay >> 2;  // first half tile row
 #pragma unroll
-        for (int j = 0; j < BLP_REGS; j++)
-            tmp[j] = *reinterpret_cast<const uint32_t *>(src + (__umul24(DESC_EXP_ROW(brow[j]), (uint32_t)pitch) + bcol[j]));
+        for (int j = 0; j < BLP_REGS; j++) {
+            const int hr = hr0 + j;
+            tmp[j] = *reinterpret_cast<const uint32_t *>(src + ((uint32_t)((hr >> 1) * (pitch * 8) + (hr & 1) * 64) + lane_src));
+        }
     };
     uint32_t *win = s_win + wv * BLP_SLOTS;
     // Rounding to the nearest integer, ties to even, by adding 1.5 * 2^23: the sum's bit pattern is
-    // 0x4b400000 + n.  A 24-bit multiply sees 0x400000 + n of it, so row * 44 + column comes out as
-    // 44 * n_row + n_col + RND_BIAS in one multiply-add of the two bit patterns.
+    // 0x4b400000 + n.  A 24-bit multiply sees 0x400000 + n of it, so row * 64 + column comes out as
+    // 64 * n_row + n_col + RND_BIAS in one multiply-add of the two bit patterns.
     const float RND = 12582912.f;
-    const uint32_t RND_BIAS = 0x400000u * (BLP_WORDS * 4) + 0x4b400000u;
-    const uint32_t ctr0 = (uint32_t)(wv * BLP_SLOTS * 4 + 18 * (BLP_WORDS * 4) + 18) - RND_BIAS;
+    const uint32_t RND_BIAS = 0x400000u * BLP_PITCH + 0x4b400000u;
+    const uint32_t ctr0 = (uint32_t)(wv * BLP_SLOTS * 4 + 18 * BLP_PITCH + 18) - RND_BIAS;
     const uint8_t *winb = reinterpret_cast<const uint8_t *>(s_win);
     uint32_t wt[BLP_REGS], wox = 0;
     if (nmine > 0)
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         const uint32_t ctr = ctr0 + wox;  // the window's offset in its first word
 #pragma unroll
         for (int j = 0; j < BLP_REGS; j++)
-            win[lane + 64 * j] = wt[j];
+            win[lane_dst + 64 * j] = wt[j];  // strip j: rows 4j .. 4j+3 of the block
         if (i + 1 < nmine)
             fetch_window(ls + 1, wt, wox);
         __builtin_amdgcn_wave_barrier();
@@ -593,8 +598,8 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
             const float q0 = __fadd_rn(__fsub_rn(__fmul_rn(pat[j].x, ca), __fmul_rn(pat[j].y, sa)), RND);
             const float r1 = __fadd_rn(__fadd_rn(__fmul_rn(pat[j].z, sa), __fmul_rn(pat[j].w, ca)), RND);
             const float q1 = __fadd_rn(__fsub_rn(__fmul_rn(pat[j].z, ca), __fmul_rn(pat[j].w, sa)), RND);
-            const uint32_t k0 = (uint32_t)__mul24(__float_as_int(r0), BLP_WORDS * 4) + __float_as_uint(q0) + ctr;
-            const uint32_t k1 = (uint32_t)__mul24(__float_as_int(r1), BLP_WORDS * 4) + __float_as_uint(q1) + ctr;
+            const uint32_t k0 = (uint32_t)__mul24(__float_as_int(r0), BLP_PITCH) + __float_as_uint(q0) + ctr;
+            const uint32_t k1 = (uint32_t)__mul24(__float_as_int(r1), BLP_PITCH) + __float_as_uint(q1) + ctr;
             const int t0 = winb[k0], t1 = winb[k1];
             bits[j] = __ballot(t0 < t1);
         }
@@ -635,12 +640,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
 {
     DescArgs a;
-    a.nlevels = g.nlevels, a.slab = g.slab, a.kp_per_frame = g.kp_per_frame, a.out_cap = g.out_cap;
+    a.nlevels = g.nlevels, a.slab = g.slab, a.bslab = g.bslab, a.kp_per_frame = g.kp_per_frame, a.out_cap = g.out_cap;
     a.batch = g.batch;
     a.l0 = b.l0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
-        a.pitch[l] = L.pitch, a.off[l] = L.off, a.kp_base[l] = L.kp_base, a.patch_size[l] = L.patch_size;
+        a.pitch[l] = L.pitch, a.off[l] = L.off, a.boff[l] = L.boff, a.kp_base[l] = L.kp_base, a.patch_size[l] = L.patch_size;
         a.scale[l] = L.scale;
     }
     const dim3 grid = orbx_frame_grid((g.out_cap + DESC_SLOTS - 1) / DESC_SLOTS, g.batch);

@@ -147,7 +147,7 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
     g->ini_th = ex->p.ini_th_fast;
     g->min_th = ex->p.min_th_fast;
     g->blur_variant = ex->p.blur_variant;
-    long long off = 0;
+    long long off = 0, boff = 0;
     int cells = 0, tiles = 0, ftiles = 0, cand = 0, kps = 0, xt = 0, yt = 0, pt = 0;
     for (int l = 0; l < g->nlevels; l++) {
         OrbxLevel &L = g->lv[l];
@@ -158,7 +158,9 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
         L.pitch = align_up(L.w, 64);
         L.off = (int)off;
         off += (long long)align_up(L.pitch * L.h, 256);
-        if (off > INT_MAX)
+        L.boff = (int)boff;
+        boff += (long long)align_up(ORBX_BLUR_LEVEL_BYTES(L.pitch, L.h), 256);
+        if (off > INT_MAX || boff > INT_MAX)
             return ORBX_E_CAPACITY;
         L.max_bx = L.w - ORBX_BORDER;
         L.max_by = L.h - ORBX_BORDER;
@@ -222,6 +224,7 @@ static int build_geometry(const orbx_extractor *ex, int w, int h, int batch, Orb
     g->kp_per_frame = kps;
     g->out_cap = kps;
     g->slab = (int)off;
+    g->bslab = (int)boff;
     return ORBX_OK;
 }
 
@@ -409,7 +412,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     OrbxBuffers &b = ex->buf;
     // 256 bytes of slack: window copies read whole words that may run past the last row
     if (e == hipSuccess) e = dmalloc(&b.pyr, B * g.slab + 256);
-    if (e == hipSuccess) e = dmalloc(&b.blur, B * g.slab + 256);
+    if (e == hipSuccess) e = dmalloc(&b.blur, B * g.bslab + 256);
     if (e == hipSuccess) e = dmalloc(&b.cell_flag, B * g.cells_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.tile_cnt, B * g.ftiles_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.tile_list, B * g.ftiles_per_frame * ORBX_TILE_CAP);
@@ -533,7 +536,7 @@ static int prepare(orbx_extractor *ex, int batch, int w, int h)
         if (rc != ORBX_OK)
             return rc;
         const OrbxGeom &c = ex->cap_geom;
-        if (g.slab > c.slab || g.cells_per_frame > c.cells_per_frame || g.cand_per_frame > c.cand_per_frame ||
+        if (g.slab > c.slab || g.bslab > c.bslab || g.cells_per_frame > c.cells_per_frame || g.cand_per_frame > c.cand_per_frame ||
             g.ftiles_per_frame > c.ftiles_per_frame ||
             g.kp_per_frame > c.kp_per_frame)
             return ORBX_E_CAPACITY;
@@ -1137,7 +1140,24 @@ extern "C" int orbx_debug_level_map(orbx_extractor *ex, int what, int frame, int
 {
     if (!ex || !dst || what != 1)
         return ORBX_E_ARG;
-    return download_level(ex, ex->buf.blur, frame, level, 0, dst, dst_stride, nullptr, nullptr);
+    if (!ex->have_batch)
+        return ORBX_E_STATE;
+    if (frame < 0 || frame >= ex->geom.batch || level < 0 || level >= ex->geom.nlevels)
+        return ORBX_E_ARG;
+    const OrbxLevel &L = ex->geom.lv[level];
+    if (dst_stride < L.w)
+        return ORBX_E_ARG;
+    // the blurred level lies in tiles: fetch its region and put the rows together here
+    HIP_TRY(hipSetDevice(ex->device));
+    std::vector<uint8_t> tiled((size_t)ORBX_BLUR_LEVEL_BYTES(L.pitch, L.h));
+    HIP_TRY(hipStreamSynchronize(ex->stream));
+    HIP_TRY(hipStreamSynchronize(ex->aux_stream));
+    HIP_TRY(hipMemcpy(tiled.data(), ex->buf.blur + (size_t)frame * ex->geom.bslab + L.boff, tiled.size(),
+                      hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; y++)
+        for (int x = 0; x < L.w; x++)
+            dst[(size_t)y * dst_stride + x] = tiled[(size_t)ORBX_BLUR_ADDR(x, y, L.pitch)];
+    return ORBX_OK;
 }
 
 extern "C" int orbx_debug_candidates(orbx_extractor *ex, int frame, int level, int *xs, int *ys, int *resp, int cap,

@@ -31,9 +31,19 @@
 // cells at least 30 px wide): capacity of a tile's candidate list
 #define ORBX_TILE_CAP 1160
 
+// Blurred levels are stored as tiles of 16 x 8 pixels = one 128-byte cache line, tile rows of pitch / 16 tiles
+// (pitch * 8 bytes), h / 8 + 2 tile rows per level.  Inside a tile: two halves of 4 rows (64 bytes), each made of
+// four groups of 4 pixels (16 bytes) holding their 4 rows one after the other.  A descriptor window (37 x 37
+// pixels) then lies in about 20 lines instead of the 50 its rows touch in a row-major level, and the blur
+// kernel's 4 x 4-pixel register block is one 16-byte store.  Byte offset of pixel (x, y) from the level's start:
+#define ORBX_BLUR_ADDR(x, y, pitch) \
+    (((y) >> 3) * ((pitch) * 8) + ((x) >> 4) * 128 + (((y) >> 2) & 1) * 64 + (((x) >> 2) & 3) * 16 + ((y) & 3) * 4 + ((x) & 3))
+#define ORBX_BLUR_LEVEL_BYTES(pitch, h) ((pitch) * 8 * ((h) / 8 + 2) + 512)
+
 struct OrbxLevel {
     int w, h, pitch;  // level size and row pitch (bytes) inside a frame slab
     int off;          // byte offset of the level inside a frame slab
+    int boff;         // byte offset of the blurred level inside a frame's blurred slab (tiled layout, below)
     int max_bx, max_by;  // w-16, h-16
     int ncols, nrows, wcell, hcell;  // cell grid of src/ORBextractor.cc:834-840 (0 when the level is too small)
     int cell_base;   // first cell of the level in the per-frame cell arrays
@@ -60,6 +70,7 @@ struct OrbxGeom {
     int cells_per_frame, tiles_per_frame, ftiles_per_frame, cand_per_frame, kp_per_frame;
     int out_cap;  // result rows per frame (== kp_per_frame)
     int slab;     // bytes per frame in the level slabs
+    int bslab;    // bytes per frame in the blurred slabs
     OrbxLevel lv[ORBX_MAX_LEVELS];
 };
 
@@ -87,7 +98,7 @@ struct OrbxLevel0 {
 struct OrbxBuffers {
     OrbxLevel0 l0;
     uint8_t *pyr;     // [batch][slab] pyramid levels (level 0 only when the frames had to be copied)
-    uint8_t *blur;    // [batch][slab] blurred levels
+    uint8_t *blur;    // [batch][bslab] blurred levels in 16 x 8-pixel tiles of one 128-byte line (ORBX_BLUR_ADDR)
     uint8_t *cell_flag;  // [batch][cells_per_frame] 1: the cell has a candidate whose score exceeds iniThFAST
     int *tile_cnt;       // [batch][ftiles_per_frame] candidates found in each FAST tile
     uint2 *tile_list;    // [batch][ftiles_per_frame][ORBX_TILE_CAP] x | y<<12 | score<<24 , order key
