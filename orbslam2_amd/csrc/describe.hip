@@ -342,21 +342,22 @@ struct DescArgs {
 
 // One workgroup per DESC_SLOTS consecutive output slots of a frame, DESC_KPW keypoints per wave.  A
 // keypoint is the same for all lanes of its wave, so the start of its windows is a scalar address and
-// a lane adds only row * pitch + 4 * word.  The windows are fetched as aligned words, 12 to a row from the
-// word at or below x - 15 or x - 18 (9 or 11 would do): the address unit works on the four lanes of a
-// quad together when their words are contiguous, and one by one when a quad straddles two rows, so rows
-// of 9 or 11 words cost 24-28 clocks per load instruction, rows of 12 a third of that; words at odd byte
-// addresses or 16-byte loads cost four times as much again (tools/ubench_ta.hip).
+// a lane adds only a fixed offset of its own.  The address unit spends a clock per 64-byte piece that a load
+// instruction touches (tools/ubench_ta.hip), and a line filled into the L1 costs two more, so both fetches
+// are shaped to touch few pieces: the orientation patch (unblurred, row-major level) as aligned words, 12 to a
+// row from the word at or below x - 15 (9 would do, but rows of 9 or 11 words cost three times as much; words
+// at odd byte addresses four times as much again); the descriptor window from the tiled blurred level as whole
+// 64-byte pieces (BLP_* above).
 // Orientation: the lane keeps its words of the 31 x 48 patch in registers, shifts each to start at
 // x - 15 with the next word from its neighbour lane, and takes two signed 4 x 8-bit dot products
 // with constant weights, u and v of the circular patch (0 outside): the sums of u * (I - 128) and
 // v * (I - 128) are m10 and m01, because u and v sum to 0 over the patch.
 // In between, one thread per keypoint evaluates cos/sin in double precision (once per keypoint instead
-// of once per lane).  Descriptor: the wave copies the 37 x 48 window into LDS and each lane samples four
+// of once per lane).  Descriptor: the wave copies the window block into LDS and each lane samples four
 // tests.  The loads of keypoint i+1 are in flight while keypoint i is computed.
-// The fetched rows may run a few bytes past the image width: that stays inside the level slabs,
-// which are allocated with slack behind the last level.
-// measurement hook: with DESC_EXP_ROWMASK=m a window row r reads image row r & ~m (fewer cache lines, wrong results)
+// The fetched patch rows may run a few bytes past the image width and the window block past the level's last
+// rows and columns: both stay inside the slabs, which are allocated with slack.
+// measurement hook: with DESC_EXP_ROWMASK=m a patch row r reads image row r & ~m (fewer cache lines, wrong results)
 #ifdef DESC_EXP_ROWMASK
 #define DESC_EXP_ROW(r) ((r) & ~(uint32_t)DESC_EXP_ROWMASK)
 #else
