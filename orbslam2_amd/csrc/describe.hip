@@ -245,15 +245,20 @@ hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
 constexpr int8_t k_pattern[1024] = {
 #include "brief_pattern.inc"
 };
-// the 256 tests as floats (x0, y0, x1, y1): a lane reads the four it evaluates with four 16-byte loads
+// the 256 tests as floats (x0, x1, y0, y1): a lane reads the four it evaluates with four 16-byte loads, and the
+// two points of a test sit side by side for the packed single-precision instructions
 struct PatternF {
     float v[1024];
 };
 constexpr PatternF make_pattern_f()
 {
     PatternF t{};
-    for (int i = 0; i < 1024; i++)
-        t.v[i] = (float)k_pattern[i];
+    for (int i = 0; i < 256; i++) {
+        t.v[4 * i + 0] = (float)k_pattern[4 * i + 0];
+        t.v[4 * i + 1] = (float)k_pattern[4 * i + 2];
+        t.v[4 * i + 2] = (float)k_pattern[4 * i + 1];
+        t.v[4 * i + 3] = (float)k_pattern[4 * i + 3];
+    }
     return t;
 }
 __constant__ __attribute__((aligned(16))) PatternF c_pattern_f = make_pattern_f();
@@ -570,10 +575,10 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     };
     uint32_t *win = s_win + wv * BLP_SLOTS;
     // Rounding to the nearest integer, ties to even, by adding 1.5 * 2^23: the sum's bit pattern is
-    // 0x4b400000 + n.  A 24-bit multiply sees 0x400000 + n of it, so row * 64 + column comes out as
-    // 64 * n_row + n_col + RND_BIAS in one multiply-add of the two bit patterns.
+    // 0x4b400000 + n.  With window rows of 64 bytes, row * 64 + column comes out as 64 * n_row + n_col + RND_BIAS
+    // (modulo 2^32) in one shift-and-add of the two bit patterns.
     const float RND = 12582912.f;
-    const uint32_t RND_BIAS = 0x400000u * BLP_PITCH + 0x4b400000u;
+    const uint32_t RND_BIAS = (0x4b400000u << 6) + 0x4b400000u;  // modulo 2^32, as the sums below
     const uint32_t ctr0 = (uint32_t)(wv * BLP_SLOTS * 4 + 18 * BLP_PITCH + 18) - RND_BIAS;
     const uint8_t *winb = reinterpret_cast<const uint8_t *>(s_win);
     uint32_t wt[BLP_REGS], wox = 0;
@@ -591,16 +596,20 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
         __builtin_amdgcn_wave_barrier();
         const float ca = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(s_ca[ls])));
         const float sa = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__float_as_int(s_sa[ls])));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 sa2 = {sa, sa}, ca2 = {ca, ca}, nsa2 = {-sa, -sa}, rnd2 = {RND, RND};
         unsigned long long bits[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             // rows x * sin + y * cos, columns x * cos - y * sin, each operation rounded (src/ORBextractor.cc:124-135)
-            const float r0 = __fadd_rn(__fadd_rn(__fmul_rn(pat[j].x, sa), __fmul_rn(pat[j].y, ca)), RND);
-            const float q0 = __fadd_rn(__fsub_rn(__fmul_rn(pat[j].x, ca), __fmul_rn(pat[j].y, sa)), RND);
-            const float r1 = __fadd_rn(__fadd_rn(__fmul_rn(pat[j].z, sa), __fmul_rn(pat[j].w, ca)), RND);
-            const float q1 = __fadd_rn(__fsub_rn(__fmul_rn(pat[j].z, ca), __fmul_rn(pat[j].w, sa)), RND);
-            const uint32_t k0 = (uint32_t)__mul24(__float_as_int(r0), BLP_PITCH) + __float_as_uint(q0) + ctr;
-            const uint32_t k1 = (uint32_t)__mul24(__float_as_int(r1), BLP_PITCH) + __float_as_uint(q1) + ctr;
+            // The two points of a test at a time in the packed single-precision instructions: every operation
+            // still rounds on its own (no contraction: the file is compiled with -ffp-contract=off), and
+            // x * cos - y * sin is x * cos + y * (-sin) exactly.
+            const f2 X = {pat[j].x, pat[j].y}, Y = {pat[j].z, pat[j].w};
+            const f2 R = (X * sa2 + Y * ca2) + rnd2;
+            const f2 Q = (X * ca2 + Y * nsa2) + rnd2;
+            const uint32_t k0 = (__float_as_uint(R.x) << 6) + __float_as_uint(Q.x) + ctr;
+            const uint32_t k1 = (__float_as_uint(R.y) << 6) + __float_as_uint(Q.y) + ctr;
             const int t0 = winb[k0], t1 = winb[k1];
             bits[j] = __ballot(t0 < t1);
         }
