@@ -367,19 +367,18 @@ __global__ __launch_bounds__(64) void k_gather(const int *__restrict__ tile_cnt,
     const int me = unit - first;
     const int *cnt = tile_cnt + (size_t)f * a.tiles_per_frame + first;
     const int lane = threadIdx.x;
-    int before = 0, all = 0;
-    for (int i = lane; i < ntiles; i += 64) {
-        const int c = cnt[i];
-        all += c;
-        before += i < me ? c : 0;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        before += __shfl_xor(before, d, 64);
-        all += __shfl_xor(all, d, 64);
-    }
+    // candidates of the level's earlier tiles (every wave), and of all its tiles (the first tile's wave only):
+    // sums over the lanes on the data-parallel-primitive path, not through LDS permutes
+    int before = 0;
+    for (int i = lane; i < me; i += 64)
+        before += cnt[i];
+    before = __builtin_amdgcn_readlane(orbx_wave_scan_add_i32(before), 63);
     const int cap = a.cand_cap[lvl];
     if (me == 0) {
+        int all = 0;
+        for (int i = lane; i < ntiles; i += 64)
+            all += cnt[i];
+        all = __builtin_amdgcn_readlane(orbx_wave_scan_add_i32(all), 63);
         if (lane == 0) {
             ncand[f * a.nlevels + lvl] = all;
             if (all > cap)
