@@ -377,6 +377,22 @@ def test_large_image_and_wide_scale_steps(oracle):
         e2.close()
 
 
+def test_maximum_image_size(oracle):
+    """The largest frame a handle accepts (4096 x 4096): tile tables, 12-bit tile coordinates and candidate
+    packing at their limits, every level against the oracle's pyramid and blurred levels."""
+    p = dict(nfeatures=3000, scale=1.2, nlevels=8, ini=20, minth=7)
+    img = orbx.synth_image(SEED + 77, 4096, 4096, 0)
+    ex = make_extractor(p, 4096, 4096)
+    kg, dg = ex(img)
+    ko, do, tr = oracle_extract(oracle, img, p, trace=True)
+    for l in range(p["nlevels"]):
+        assert np.array_equal(ex.pyramid_level(0, l), tr["levels"][l]), l
+        if tr["blur"][l] is not None:
+            assert np.array_equal(ex.debug_level_map(1, 0, l), tr["blur"][l]), "blur level %d" % l
+    compare_frame(kg, dg, ko, do)
+    ex.close()
+
+
 def test_batch_download_all_equals_per_frame(oracle):
     w, h, B = 640, 480, 9   # nine frames: the staging copy runs on several threads
     imgs = [orbx.synth_image(SEED + 31 * i, w, h, 0 if i != 4 else 1) for i in range(B)]
