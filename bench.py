@@ -108,23 +108,43 @@ def main():
     ap.add_argument("--pcie-only", action="store_true", help="only the host-memory-to-host-memory measurement")
     ap.add_argument("--pcie-instances", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: the ranks only form the process group, pass the barriers and the reductions of "
+                         "the timed region and rank 0 prints a line with value null (checks the launch on a CPU box)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Called without a launcher: this process has not touched the GPU (nothing above imports torch), so it
+        # may start the ranks as children.  It never becomes a rank itself.
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        # a line that says n_gpus = N must come from N ranks
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to run\n"
+                         % (args.gpus, world))
+        raise SystemExit(2)
     # ORBX_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers, all-gather) even
     # with one rank, to rehearse it with the nccl backend on a one-GPU box
     dist_path = world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
+    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")  # "gloo" rehearses the N>1 path on one GPU
+    share_gpu = os.environ.get("ORBX_BENCH_SHARE_GPU") == "1"  # rehearsal: more ranks than GPUs, ranks share devices
     import torch
     import torch.distributed as dist
 
+    if args.dry_run:
+        return dry_run(args, torch, dist, rank, world, dist_path)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the only path")
-    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals) ranks share devices
-    local_rank = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if ndev < world and not (share_gpu and backend != "nccl"):
+        sys.stderr.write("bench.py: %d ranks but %d GPU(s) visible; one rank per GPU (a rehearsal with ranks sharing a "
+                         "GPU needs ORBX_BENCH_SHARE_GPU=1 and ORBX_BENCH_BACKEND=gloo)\n" % (world, ndev))
+        raise SystemExit(2)
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
-    backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")  # "gloo" rehearses the N>1 path on one GPU
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -132,6 +152,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            sys.stderr.write("bench.py: process group of %d ranks for --gpus %d\n" % (dist.get_world_size(), args.gpus))
+            raise SystemExit(2)
 
     import orbslam2_amd as orbx
 
@@ -265,7 +288,8 @@ def main():
 
     out = {
         "metric": "ORB frames/s @KITTI 1241x376 2000 kp (1/8 GPU); Hamming matches/s; % roofline",
-        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "ranks": dist.get_world_size() if dist_path else 1,
+        "backend": backend if dist_path else None, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": args.workload, "frames_per_step_per_gpu": batch, "extractor_instances": ninst,
@@ -304,6 +328,46 @@ def main():
         out["speedup_vs_cpu_baseline"] = round(fps / world / out["cpu_baseline"]["value"], 1)
         out["speedup_vs_cpu_baseline_what"] = "frames/s of one GPU over frames/s of one host core"
     print(json.dumps(out), flush=True)
+
+
+def launch_ranks(n):
+    """Starts `n` ranks of this script (one per GPU) through torch.distributed.run as a child process, relays
+    their output (rank 0 prints the JSON line) and returns the child's exit status, which is non-zero if any
+    rank failed.  The parent stays off the GPU and is not replaced: it waits."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, torch, dist, rank, world, dist_path):
+    """The launch and the collectives of the timed region without any GPU work (gloo)."""
+    if dist_path:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(2)
+        dist.barrier()
+    t0 = time.perf_counter()
+    el = torch.tensor([time.perf_counter() - t0 + 1e-6 * (rank + 1)], dtype=torch.float64)
+    if dist_path:
+        dist.barrier()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ranks = dist.get_world_size() if dist_path else 1
+    if dist_path:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "ORB frames/s @KITTI 1241x376 2000 kp (1/8 GPU); Hamming matches/s; % roofline",
+                          "value": None, "unit": "frames/s", "n_gpus": world, "ranks": ranks,
+                          "backend": "gloo" if dist_path else None, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "max_over_ranks_s": float(el.item())}), flush=True)
 
 
 SHARDED_HAMMING_LIMIT_S = 150
