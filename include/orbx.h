@@ -27,7 +27,8 @@ enum {
     ORBX_E_GEOMETRY = -4,  /* image too tall for the quadtree: round(width/height) of a level is 0
                               (the reference divides by zero there, src/ORBextractor.cc:584-589) */
     ORBX_E_NODEVICE = -5,  /* no usable GPU */
-    ORBX_E_STATE = -6      /* call order violated (no batch extracted yet, ...) */
+    ORBX_E_STATE = -6,     /* call order violated (no batch extracted yet, ...) */
+    ORBX_E_RCCL = -7       /* RCCL is not installed or one of its calls failed (orbx_sharded_last_error has the text) */
 };
 const char *orbx_strerror(int code);
 int orbx_last_hip_error(void);
@@ -245,6 +246,36 @@ int orbx_top2_merge(int nshards, int nq, const int32_t *best_idx, const uint16_t
  * Asynchronous on the matcher's stream. */
 int orbx_top2_merge_shards_device(orbx_matcher *m, int nshards, int nq, const uint8_t *d_blocks,
                                   int64_t shard_stride_bytes, int32_t *d_best_idx, uint16_t *d_d1, uint16_t *d_d2);
+/* The brute-force top-2 against a database whose rows are sharded over the GPUs of a node, for a C++ caller
+ * with one thread or process per GPU (the reference has no such step: Tracking::Relocalization,
+ * src/Tracking.cc:1554-1590, runs SearchByBoW per candidate key frame on one core; this is that inner loop,
+ * src/ORBmatcher.cc:217-249, over a flat database too large or too hot for one GPU).  Rank r holds the
+ * contiguous rows [idx_base, idx_base + shard_rows) of the database and all queries.  A call runs the top-2
+ * kernel on the shard, one ncclAllGather (RCCL over xGMI) of 8 bytes per query and rank, and the merge kernel
+ * of orbx_top2_merge_shards_device, all on one stream: every rank ends up with the result of a single pass
+ * over the whole database (ties go to the lower row).  Shards must be in ascending row order by rank.
+ * RCCL is looked up when the first of these functions is called (dlopen of librccl.so.1; the environment
+ * variable ORBX_RCCL_LIB names another file); without it they return ORBX_E_RCCL and the rest of the
+ * library is unaffected.
+ *   orbx_sharded_unique_id       rank 0 calls it and hands the ORBX_RCCL_UNIQUE_ID_BYTES bytes to the other
+ *                                ranks by its own means (the ncclUniqueId of ncclGetUniqueId)
+ *   orbx_sharded_matcher_create  collective: every rank calls it with the same id (ncclCommInitRank)
+ *   orbx_match_top2_sharded_device  collective; device pointers; asynchronous on the handle's stream (its own
+ *                                unless set): order the inputs before it and wait for that stream, or call
+ *                                orbx_sharded_matcher_synchronize, before reading the results.  nq <= max_queries. */
+#define ORBX_RCCL_UNIQUE_ID_BYTES 128
+typedef struct orbx_sharded_matcher orbx_sharded_matcher;
+int orbx_sharded_unique_id(void *id_out);
+int orbx_sharded_matcher_create(int device, int rank, int world, const void *unique_id, int max_queries,
+                                orbx_sharded_matcher **out);
+void orbx_sharded_matcher_destroy(orbx_sharded_matcher *sm);
+int orbx_sharded_matcher_set_stream(orbx_sharded_matcher *sm, void *hip_stream);
+int orbx_sharded_matcher_synchronize(orbx_sharded_matcher *sm);
+int orbx_match_top2_sharded_device(orbx_sharded_matcher *sm, const uint8_t *d_queries, int nq, const uint8_t *d_shard,
+                                   int64_t shard_rows, int64_t idx_base, int32_t *d_best_idx, uint16_t *d_d1,
+                                   uint16_t *d_d2);
+const char *orbx_sharded_last_error(void);
+
 /* Acceptance rule of src/ORBmatcher.cc:245-249: d1 <= th && (float)d1 < ratio*(float)d2.
  * accept[i] = 1/0; returns the number accepted. Host function. */
 int orbx_ratio_test(int nq, const uint16_t *d1, const uint16_t *d2, int th, float ratio, uint8_t *accept);

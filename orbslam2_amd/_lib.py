@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liborbx.so")
 
 NSTAGES = 6
-OK, E_ARG, E_HIP, E_CAPACITY, E_GEOMETRY, E_NODEVICE, E_STATE = 0, -1, -2, -3, -4, -5, -6
+OK, E_ARG, E_HIP, E_CAPACITY, E_GEOMETRY, E_NODEVICE, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class OrbxError(RuntimeError):
@@ -21,6 +21,8 @@ class OrbxError(RuntimeError):
         msg = lib().orbx_strerror(code).decode()
         if code == E_HIP:
             msg += " (hipError %d)" % lib().orbx_last_hip_error()
+        if code == E_RCCL:
+            msg += " (%s)" % lib().orbx_sharded_last_error().decode()
         super().__init__("%s: %s [%d]" % (where, msg, code))
 
 
@@ -79,6 +81,13 @@ SIGNATURES = {
     "orbx_match_top2": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P, _P, _P]),
     "orbx_top2_merge": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
     "orbx_top2_merge_shards_device": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64, _P, _P, _P]),
+    "orbx_sharded_unique_id": (C.c_int, [_P]),
+    "orbx_sharded_matcher_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.POINTER(_P)]),
+    "orbx_sharded_matcher_destroy": (None, [_P]),
+    "orbx_sharded_matcher_set_stream": (C.c_int, [_P, _P]),
+    "orbx_sharded_matcher_synchronize": (C.c_int, [_P]),
+    "orbx_match_top2_sharded_device": (C.c_int, [_P, _P, C.c_int, _P, C.c_int64, C.c_int64, _P, _P, _P]),
+    "orbx_sharded_last_error": (C.c_char_p, []),
     "orbx_ratio_test": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_float, _P]),
     "orbx_search_for_initialization": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_float, C.c_float,
                                                  C.c_float, C.c_float, _P, C.c_int, C.c_float, C.c_int, _P,

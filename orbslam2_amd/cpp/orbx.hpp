@@ -131,6 +131,60 @@ struct Bounds {
     float min_x, max_x, min_y, max_y;
 };
 
+// The brute-force top-2 against a database sharded over the GPUs of a node (one thread or process per
+// GPU): rank r holds the contiguous rows [idx_base, idx_base + shard_rows) in device memory and all
+// queries; match() runs the shard's top-2, one RCCL all-gather of 8 bytes per query and rank and the
+// merge, and every rank gets the result of a single pass over the whole database (the bookkeeping of
+// src/ORBmatcher.cc:217-242: strict '<', the first row wins ties).  unique_id() on rank 0, handed to
+// the other ranks by the caller's own means, then the constructor on every rank (collective).
+class ShardedMatcher {
+public:
+    typedef std::vector<uint8_t> UniqueId;
+    static UniqueId unique_id()
+    {
+        UniqueId id(ORBX_RCCL_UNIQUE_ID_BYTES);
+        const int rc = orbx_sharded_unique_id(id.data());
+        if (rc < 0)
+            throw Error(rc, orbx_sharded_last_error());
+        return id;
+    }
+    ShardedMatcher(int device, int rank, int world, const UniqueId &id, int max_queries = 4096, float nnratio = 0.75f)
+        : nnratio_(nnratio), max_queries_(max_queries)
+    {
+        if (id.size() != ORBX_RCCL_UNIQUE_ID_BYTES)
+            throw Error(ORBX_E_ARG, "ShardedMatcher: unique id size");
+        const int rc = orbx_sharded_matcher_create(device, rank, world, id.data(), max_queries, &h_);
+        if (rc < 0)
+            throw Error(rc, rc == ORBX_E_RCCL ? orbx_sharded_last_error() : "orbx_sharded_matcher_create");
+    }
+    ~ShardedMatcher() { orbx_sharded_matcher_destroy(h_); }
+    ShardedMatcher(const ShardedMatcher &) = delete;
+    ShardedMatcher &operator=(const ShardedMatcher &) = delete;
+    orbx_sharded_matcher *handle() { return h_; }
+    void set_stream(void *hip_stream) { check(orbx_sharded_matcher_set_stream(h_, hip_stream), "set_stream"); }
+    void synchronize() { check(orbx_sharded_matcher_synchronize(h_), "orbx_sharded_matcher_synchronize"); }
+    // device pointers; asynchronous on the handle's stream (collective: every rank calls it)
+    void match_device(const uint8_t *d_queries, int nq, const uint8_t *d_shard, int64_t shard_rows, int64_t idx_base,
+                      int32_t *d_best, uint16_t *d_d1, uint16_t *d_d2)
+    {
+        const int rc = orbx_match_top2_sharded_device(h_, d_queries, nq, d_shard, shard_rows, idx_base, d_best, d_d1, d_d2);
+        if (rc < 0)
+            throw Error(rc, rc == ORBX_E_RCCL ? orbx_sharded_last_error() : "orbx_match_top2_sharded_device");
+    }
+    // d1 <= th && d1 < nnratio * d2 (src/ORBmatcher.cc:245-249) on downloaded distances
+    int ratio_test(const std::vector<uint16_t> &d1, const std::vector<uint16_t> &d2, std::vector<uint8_t> &accept,
+                   int th = ORBX_TH_LOW) const
+    {
+        accept.resize(d1.size());
+        return orbx_ratio_test((int)d1.size(), d1.data(), d2.data(), th, nnratio_, accept.data());
+    }
+
+private:
+    orbx_sharded_matcher *h_ = nullptr;
+    float nnratio_;
+    int max_queries_;
+};
+
 // orbx::Matcher carries the two constructor arguments of ORB_SLAM2::ORBmatcher (nnratio, checkOri;
 // include/ORBmatcher.h:41) and the device workspace of the searches.  Methods named like the
 // reference's run the same search on plain arrays: frames are (keypoints, descriptors) pairs, map

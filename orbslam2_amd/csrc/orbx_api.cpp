@@ -33,6 +33,7 @@ extern "C" const char *orbx_strerror(int code)
     case ORBX_E_GEOMETRY: return "image too tall for the quadtree (round(width/height) is 0)";
     case ORBX_E_NODEVICE: return "no usable GPU";
     case ORBX_E_STATE: return "call order violated";
+    case ORBX_E_RCCL: return "RCCL missing or failed";
     default: return "unknown error";
     }
 }

@@ -109,6 +109,71 @@ class ShardedMatcher:
         return ORBmatcher.merge_top2(host[:, :, 0], host[:, :, 1].astype(np.uint16), host[:, :, 2].astype(np.uint16))
 
 
+class RcclShardedMatcher:
+    """The library's own sharded matcher (orbx_sharded_* in include/orbx.h): per-shard top-2, ncclAllGather
+    and merge enqueued by C code on one HIP stream, the path a C++ caller takes.  Python only carries the
+    128-byte communicator id from rank 0 to the other ranks (`exchange_id`: a callable that takes rank 0's
+    bytes, or None on other ranks, and returns rank 0's bytes everywhere; default: a torch.distributed
+    broadcast over the default group).  One rank per GPU: RCCL rejects two ranks on one device."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank, world, device, max_queries=4096, exchange_id=None):
+        import ctypes as C
+
+        from . import _lib as L
+        self._L, self._C = L, C
+        lib = L.lib()
+        buf = (C.c_uint8 * self.ID_BYTES)()
+        if rank == 0:
+            L.check(lib.orbx_sharded_unique_id(buf), "orbx_sharded_unique_id")
+        raw = bytes(buf)
+        if world > 1:
+            raw = (exchange_id or _broadcast_bytes)(raw if rank == 0 else None)
+        assert len(raw) == self.ID_BYTES
+        self._h = C.c_void_p()
+        idbuf = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(raw)
+        L.check(lib.orbx_sharded_matcher_create(device, rank, world, idbuf, max_queries, C.byref(self._h)),
+                "orbx_sharded_matcher_create")
+        self.rank, self.world = rank, world
+
+    def set_stream(self, hip_stream):
+        self._L.check(self._L.lib().orbx_sharded_matcher_set_stream(self._h, self._C.c_void_p(hip_stream)),
+                      "orbx_sharded_matcher_set_stream")
+
+    def match_device(self, d_queries, nq, d_shard, shard_rows, idx_base, d_best, d_d1, d_d2):
+        """Device addresses (ints); asynchronous on the handle's stream; collective."""
+        P = self._C.c_void_p
+        self._L.check(self._L.lib().orbx_match_top2_sharded_device(self._h, P(d_queries), nq, P(d_shard), shard_rows,
+                                                                  idx_base, P(d_best), P(d_d1), P(d_d2)),
+                      "orbx_match_top2_sharded_device")
+
+    def synchronize(self):
+        self._L.check(self._L.lib().orbx_sharded_matcher_synchronize(self._h), "orbx_sharded_matcher_synchronize")
+
+    def close(self):
+        if self._h:
+            self._L.lib().orbx_sharded_matcher_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _broadcast_bytes(raw):
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.zeros(RcclShardedMatcher.ID_BYTES, dtype=torch.uint8, device=dev)
+    if raw is not None:
+        t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().numpy().tobytes())
+
+
 def _as_i32(v):
     import torch
     if torch.is_tensor(v):

@@ -1,4 +1,6 @@
 """GPU parity of the matcher through the C ABI: indices and distances bit-exact against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -665,3 +667,37 @@ def test_search_by_projection_edges(oracle):
     onm, omatch, ofm = oracle.search_by_projection(sub, desc[:200], bounds, x, y, r, np.array([0], np.int32),
                                                    np.array([-1], np.int32), desc[150:151], 0.8, use_second=False)
     assert nm == onm == 1 and list(match) == list(omatch) == [150] and np.array_equal(fm, ofm)
+
+
+def test_rccl_sharded_matcher_c_abi(oracle):
+    """orbx_sharded_* (the C path: top-2, ncclAllGather on the same stream, merge) with a real RCCL communicator
+    of one rank, from Python and from the C++ program (which also checks a host loop with the reference's
+    bookkeeping, src/ORBmatcher.cc:217-242).  More ranks need more GPUs: RCCL takes one rank per device."""
+    import subprocess
+
+    import torch
+    from orbslam2_amd.sharded import RcclShardedMatcher
+    ndb, nq = 30011, 501
+    db, q = make_db(ndb, nq, seed=9)
+    db[25000:25003] = q[3]
+    d_db, d_q = torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda()
+    best = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    sm = RcclShardedMatcher(0, 1, 0, max_queries=nq)
+    ob, o1, o2 = oracle.match_top2(q, db)
+    for n in (nq, 77):  # the second call smaller: the blocks are laid out for the call's own query count
+        sm.match_device(d_q.data_ptr(), n, d_db.data_ptr(), ndb, 0, best.data_ptr(), d1.data_ptr(), d2.data_ptr())
+        sm.synchronize()
+        assert np.array_equal(best.cpu().numpy()[:n], ob[:n])
+        assert np.array_equal(d1.cpu().numpy().view(np.uint16)[:n], o1[:n])
+        assert np.array_equal(d2.cpu().numpy().view(np.uint16)[:n], o2[:n])
+    sm.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "test_sharded_rccl")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    out = subprocess.run([exe, "1", "333", "20000"], capture_output=True, text=True, timeout=110)
+    # RCCL prints a version banner on the same stream first
+    assert out.returncode == 0 and any(ln.startswith("OK world=1") for ln in out.stdout.splitlines()), \
+        out.stdout + out.stderr
