@@ -569,25 +569,48 @@ def bench_config5(orbx, torch, dist, rank, world, w, h, nfeat, block, stride, co
 
 def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
     """2000 queries x 1M rows, rows sharded over the ranks, per-shard top-2 exchanged with one all-gather
-    (RCCL) and merged on every rank."""
-    from orbslam2_amd.sharded import ShardedMatcher, shard_bounds
+    (RCCL) and merged on every rank.  With the nccl backend the whole step is the library's C path
+    (orbx_match_top2_sharded_device: kernels and ncclAllGather enqueued by C code on one stream); a gloo
+    rehearsal, where ranks share a GPU and RCCL cannot run, exchanges the blocks through torch."""
+    from orbslam2_amd.sharded import RcclShardedMatcher, ShardedMatcher, shard_bounds
     nq, ndb = 2000, 1_000_000
     lo, hi = shard_bounds(ndb, rank, world)
     full, q, _ = config4_data(orbx, nq, ndb)
     db = torch.from_numpy(full[lo:hi].copy()).cuda()
     dq = torch.from_numpy(q).cuda()
-    # the matcher on this rank's GPU: its launches make that device current
-    m = orbx.ORBmatcher(0.75, device=torch.cuda.current_device())
-    sm = ShardedMatcher(None, rank, world, device=coll_dev, matcher=m)
+    c_path = coll_dev == "cuda"
+    if c_path:
+        sm = RcclShardedMatcher(rank, world, torch.cuda.current_device(), max_queries=nq)
+        best = torch.zeros(nq, dtype=torch.int32, device="cuda")
+        d1 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+        d2 = torch.zeros(nq, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()  # inputs complete before the handle's own stream reads them
+
+        def run():
+            sm.match_device(dq.data_ptr(), nq, db.data_ptr(), hi - lo, lo, best.data_ptr(), d1.data_ptr(), d2.data_ptr())
+            return best, d1, d2
+
+        def sync():
+            sm.synchronize()
+    else:
+        # the matcher on this rank's GPU: its launches make that device current
+        m = orbx.ORBmatcher(0.75, device=torch.cuda.current_device())
+        tm = ShardedMatcher(None, rank, world, device=coll_dev, matcher=m)
+
+        def run():
+            return tm.match_device(dq, nq, db, hi - lo, lo)
+
+        def sync():
+            torch.cuda.synchronize()
     for _ in range(3):
-        res = sm.match_device(dq, nq, db, hi - lo, lo)
-    torch.cuda.synchronize()
+        res = run()
+    sync()
     dist.barrier()
     reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
-        res = sm.match_device(dq, nq, db, hi - lo, lo)
-    torch.cuda.synchronize()
+        res = run()
+    sync()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     sec = float(dt.item()) / reps
@@ -597,9 +620,15 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
         for i in range(0, nq, nq // 20):
             ok = ok and numpy_top2(q[i], full) == (int(res[0][i]), int(res[1][i]), int(res[2][i]))
     del full
+    if c_path:
+        sm.close()
     rate = nq * ndb / sec
     return {"pairs_per_s": rate, "ms_per_call": round(sec * 1e3, 4), "queries": nq, "database_rows": ndb,
-            "shards": world, "exchange": "all_gather of 8 B per query and rank into device memory, merge kernel", "self_check": ok,
+            "shards": world,
+            "exchange": ("orbx_match_top2_sharded_device: ncclAllGather of 8 B per query and rank on the kernels' stream, "
+                         "merge kernel" if c_path else
+                         "torch all_gather of 8 B per query and rank through host memory (gloo), merge kernel"),
+            "self_check": ok,
             "roofline": {"bound": "mfma", "dtype": "fp4", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12 / world, 1),
                          "peak": round(MFMA_F4_MAC_PER_S * 2 / 1e12, 1), "unit": "TFLOP/s per GPU",
                          "frac": round(rate / world * MAC_PER_PAIR / MFMA_F4_MAC_PER_S, 4)}}
