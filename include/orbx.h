@@ -145,6 +145,11 @@ int orbx_extractor_stage_times(orbx_extractor *ex, float *ms_sum /* ORBX_NSTAGES
  * src/ORBextractor.cc:1199-1219). */
 int orbx_pyramid_level(orbx_extractor *ex, int frame, int level, int border, uint8_t *dst, int dst_stride,
                        int *width, int *height);
+/* Lifetime: after orbx_extract_batch_device read the frames in place (4-byte aligned address and strides),
+ * level 0 of the pyramid IS the caller's device memory: orbx_pyramid_level(.., 0, ..) and
+ * orbx_pyramid_download read it again, so the frames of the last device batch must stay valid and unchanged
+ * until the pyramid has been fetched.  Host-frame calls (orbx_extract, orbx_extract_batch_host) keep their own
+ * device copy and have no such requirement. */
 
 /* The whole of mvImagePyramid for one frame of the last batch in one round trip (what
  * ORBextractor::ComputePyramid leaves behind, src/ORBextractor.cc:1191-1221): level l is written as a

@@ -219,6 +219,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             out[j] = lo | hi;
         }
         const int y0 = ty0 + 4 * rb;
+        if (ty0 + ORBX_FT_H > h) {
+            // bottom tile of the level (uniform branch): rows below the level were filtered from unstaged rows;
+            // they land in the padding tile rows, which stay zero instead of run-dependent bytes
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                out[j] = y0 + j < h ? out[j] : 0u;
+        }
         *reinterpret_cast<uint4 *>(dst + (uint32_t)ORBX_BLUR_ADDR(x, y0, pitch)) = make_uint4(out[0], out[1], out[2], out[3]);
     }
 }

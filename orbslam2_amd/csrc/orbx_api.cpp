@@ -694,6 +694,21 @@ extern "C" int orbx_extract_batch_host(orbx_extractor *ex, const uint8_t *const 
         for (int f = 2; f < batch && even; f++)
             even = images[f] - images[f - 1] == dist;
         even = even && dist >= (ptrdiff_t)src_bytes && (dist & 3) == 0 && dist <= (ptrdiff_t)src_bytes + (1 << 16);
+        if (even) {
+            // Equal distances do not make one allocation: frames pinned one by one often lie evenly spaced
+            // too (consecutive hipHostMalloc calls, the power-of-two blocks of a caching allocator).  One copy
+            // may only span memory of a single allocation, so ask the runtime for the allocation around the
+            // first frame and require the last frame's end inside it.
+            void *base = nullptr;
+            size_t size = 0;
+            if (hipMemGetAddressRange((hipDeviceptr_t *)&base, &size, (hipDeviceptr_t)images[0]) != hipSuccess) {
+                (void)hipGetLastError();
+                even = false;
+            } else {
+                const uint8_t *lo = static_cast<const uint8_t *>(base);
+                even = images[0] >= lo && images[batch - 1] + src_bytes <= lo + size;
+            }
+        }
         const size_t fstride = even ? (size_t)dist : (src_bytes + 255) / 256 * 256;
         const size_t need = fstride * (size_t)batch;
         if (ex->d_stage_bytes < need) {

@@ -35,7 +35,9 @@
 // (pitch * 8 bytes), h / 8 + 2 tile rows per level.  Inside a tile: two halves of 4 rows (64 bytes), each made of
 // four groups of 4 pixels (16 bytes) holding their 4 rows one after the other.  A descriptor window (37 x 37
 // pixels) then lies in about 20 lines instead of the 50 its rows touch in a row-major level, and the blur
-// kernel's 4 x 4-pixel register block is one 16-byte store.  Byte offset of pixel (x, y) from the level's start:
+// kernel's 4 x 4-pixel register block is one 16-byte store.  Rows below the level inside its last tile row are
+// written as zeros; the padding tile rows behind it and the columns right of the level hold unspecified bytes.
+// Byte offset of pixel (x, y) from the level's start:
 #define ORBX_BLUR_ADDR(x, y, pitch) \
     (((y) >> 3) * ((pitch) * 8) + ((x) >> 4) * 128 + (((y) >> 2) & 1) * 64 + (((x) >> 2) & 3) * 16 + ((y) & 3) * 4 + ((x) & 3))
 #define ORBX_BLUR_LEVEL_BYTES(pitch, h) ((pitch) * 8 * ((h) / 8 + 2) + 512)

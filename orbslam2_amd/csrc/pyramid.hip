@@ -56,7 +56,9 @@ typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
 //
 // resize_rows: destination rows dy0 .. dy1-1 (wave-uniform) of the lane's columns dx0 .. dx0+3.  `sbase`
 // points at source pixel (0, 0) (global memory or LDS); `put(dy, word)` receives the four result bytes of a row.
-template <typename Put>
+// LdsSrc: the source is a staged tile in LDS (every 12-byte read that starts at a lane's own first word stays
+// inside the array by construction of its margins; `src_bytes` is not a limit there).
+template <bool LdsSrc = false, typename Put>
 __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, uint32_t src_bytes, int dx0, int dy0,
                                             int dy1, const OrbxXCoef *__restrict__ xt,
                                             const OrbxYCoef *__restrict__ yt, Put put)
@@ -77,7 +79,9 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
     // horizontal pass of one source row, (S[sx] * a0 + S[sx + 1] * a1) >> 4 for the lane's four pixels (the shift
     // is the vertical pass's, applied once per source row here), from the three words `w` loaded ahead (narrow
     // lanes) or from single bytes
-    const uint32_t wb_safe = narrow ? wb : 0u;  // other lanes load the words at the row's start and ignore them
+    // other lanes load words they ignore: at the row's start in global memory (always readable), at their own
+    // first word in LDS (the row's start may lie before the array there)
+    const uint32_t wb_safe = (narrow || LdsSrc) ? wb : 0u;
     auto load_row = [&](int srow, uint32_t (&w)[3]) {
         const uint32_t *row =
             reinterpret_cast<const uint32_t *>(sbase + __umul24((uint32_t)srow, (uint32_t)spitch) + wb_safe);
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void k_resize_pair(const uint8_t *__restrict__
         const bool whole = gx0 >= x2a && gx0 + 4 <= x2b;
         // LDS address of middle-level pixel (0, 0): pixel (X, Y) lies at mid[(Y - Y1) * RS2_PITCH + RS2_PAD + X - X1]
         const uint8_t *origin = mid + RS2_PAD - X1 - Y1 * RS2_PITCH;
-        resize_rows(origin, RS2_PITCH, 0xffffffffu, gx0, ry0, min(ry0 + RS_ROWS, y2b), txt, tyt, [&](int dy, uint32_t out) {
+        resize_rows<true>(origin, RS2_PITCH, 0xffffffffu, gx0, ry0, min(ry0 + RS_ROWS, y2b), txt, tyt, [&](int dy, uint32_t out) {
             uint8_t *d = tbase + (uint32_t)(__umul24(dy, tpitch) + gx0);
             if (whole) {
                 *reinterpret_cast<uint32_t *>(d) = out;

@@ -356,7 +356,8 @@ def test_scale_tables_match_oracle(oracle):
 
 def test_large_image_and_wide_scale_steps(oracle):
     """Full-HD frame with many features (level 0 exceeds the register-cached quadtree path), and scale
-    factors whose resize takes the widest source windows (2.0) and the byte-wise path (2.6)."""
+    factors whose resize takes the widest source windows (2.0), the byte-wise path (2.6), and in between (2.3, 2.45)
+    the fused two-level kernel of single calls with lanes whose source span exceeds the word path's."""
     p = dict(nfeatures=5000, scale=1.2, nlevels=8, ini=20, minth=7)
     img = orbx.synth_image(SEED + 21, 1920, 1080, 0)
     ex = make_extractor(p, 1920, 1080)
@@ -365,7 +366,7 @@ def test_large_image_and_wide_scale_steps(oracle):
     compare_frame(kg, dg, ko, do)
     assert len(kg) >= 5000
     ex.close()
-    for sc, nl in [(2.0, 4), (2.6, 3)]:
+    for sc, nl in [(2.0, 4), (2.6, 3), (2.3, 3), (2.45, 3)]:
         p = dict(nfeatures=1500, scale=sc, nlevels=nl, ini=20, minth=7)
         img = orbx.synth_image(SEED + nl, 1280, 720, 0)
         e2 = make_extractor(p, 1280, 720)
@@ -405,6 +406,53 @@ def test_batch_download_all_equals_per_frame(oracle):
     ko, do = oracle_extract(oracle, imgs[7], TUM)
     compare_frame(both[7][0], both[7][1], ko, do)
     assert len(both[4][0]) == 0
+
+
+def test_separately_pinned_frames_at_equal_distances():
+    """Frames pinned one by one often lie at equal distances (a caching pinned allocator hands out equal
+    blocks) without sharing an allocation: they must travel as one copy per frame, not as one copy across the
+    gaps between allocations.  Same results as pageable frames."""
+    import ctypes as C
+    import torch
+    from orbslam2_amd import _lib as L
+    w, h, B = 1241, 376, 6
+    imgs = [orbx.synth_image(SEED + 31 * i, w, h, 0) for i in range(B)]
+    lib = L.lib()
+    ex = make_extractor(KITTI, w, h, batch=B)
+    ex.extract_batch_host(imgs)
+    ref = ex.batch_download_all()
+    # (a) torch's pinned allocator, one tensor per frame
+    tens = [torch.empty((h, w), dtype=torch.uint8).pin_memory() for _ in range(B)]
+    for t, im in zip(tens, imgs):
+        t.numpy()[:] = im
+    ex.extract_batch_host([t.numpy() for t in tens])
+    got = ex.batch_download_all()
+    for f in range(B):
+        assert np.array_equal(ref[f][0], got[f][0]) and np.array_equal(ref[f][1], got[f][1])
+    # (b) frames of one pageable array registered one by one (hipHostRegister): evenly spaced by construction,
+    # page-locked each, and no single allocation spans them
+    import os
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))  # the runtime already loaded
+    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    hip.hipHostUnregister.argtypes = [C.c_void_p]
+    fbytes = (h * w + 4095) // 4096 * 4096 + 4096  # a page of unregistered memory between frames
+    raw = np.zeros(B * fbytes + 4096, np.uint8)
+    base = (raw.ctypes.data + 4095) // 4096 * 4096 - raw.ctypes.data
+    views = []
+    for f in range(B):
+        v = raw[base + f * fbytes: base + f * fbytes + h * w].reshape(h, w)
+        v[:] = imgs[f]
+        assert hip.hipHostRegister(v.ctypes.data, h * w, 0) == 0
+        views.append(v)
+    try:
+        ex.extract_batch_host(views)
+        got = ex.batch_download_all()
+    finally:
+        for v in views:
+            hip.hipHostUnregister(v.ctypes.data)
+    for f in range(B):
+        assert np.array_equal(ref[f][0], got[f][0]) and np.array_equal(ref[f][1], got[f][1])
+    ex.close()
 
 
 @pytest.mark.parametrize("w,h", [(640, 480), (333, 217)])
