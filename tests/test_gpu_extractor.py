@@ -429,27 +429,25 @@ def test_separately_pinned_frames_at_equal_distances():
     got = ex.batch_download_all()
     for f in range(B):
         assert np.array_equal(ref[f][0], got[f][0]) and np.array_equal(ref[f][1], got[f][1])
-    # (b) frames of one pageable array registered one by one (hipHostRegister): evenly spaced by construction,
-    # page-locked each, and no single allocation spans them
+    # (b) one hipHostMalloc per frame: consecutive allocations of one size, usually at equal distances
     import os
     hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))  # the runtime already loaded
-    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
-    hip.hipHostUnregister.argtypes = [C.c_void_p]
-    fbytes = (h * w + 4095) // 4096 * 4096 + 4096  # a page of unregistered memory between frames
-    raw = np.zeros(B * fbytes + 4096, np.uint8)
-    base = (raw.ctypes.data + 4095) // 4096 * 4096 - raw.ctypes.data
-    views = []
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipHostFree.argtypes = [C.c_void_p]
+    ptrs, views = [], []
     for f in range(B):
-        v = raw[base + f * fbytes: base + f * fbytes + h * w].reshape(h, w)
+        p = C.c_void_p()
+        assert hip.hipHostMalloc(C.byref(p), h * w, 0) == 0
+        ptrs.append(p)
+        v = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(h, w))
         v[:] = imgs[f]
-        assert hip.hipHostRegister(v.ctypes.data, h * w, 0) == 0
         views.append(v)
     try:
         ex.extract_batch_host(views)
         got = ex.batch_download_all()
     finally:
-        for v in views:
-            hip.hipHostUnregister(v.ctypes.data)
+        for p in ptrs:
+            hip.hipHostFree(p)
     for f in range(B):
         assert np.array_equal(ref[f][0], got[f][0]) and np.array_equal(ref[f][1], got[f][1])
     ex.close()

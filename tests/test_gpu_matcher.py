@@ -701,3 +701,55 @@ def test_rccl_sharded_matcher_c_abi(oracle):
     # RCCL prints a version banner on the same stream first
     assert out.returncode == 0 and any(ln.startswith("OK world=1") for ln in out.stdout.splitlines()), \
         out.stdout + out.stderr
+
+
+def test_hand_worked_cases_through_the_hip_path():
+    """The paper cases of tests/kat_cases.py (the only pins of SearchForInitialization and GetFeaturesInArea that
+    do not come from the oracle) through the C ABI: host-array forms, and the device batch form of the search."""
+    import torch
+    import kat_cases as K
+    from orbslam2_amd import _lib as L
+    kps, cells, queries = K.features_in_area_case()
+    q = np.array([a for a, _ in queries], np.float32)
+    m = orbx.ORBmatcher(0.9, True)
+    lists, cs, ci = m.GetFeaturesInArea(kps, K.BOUNDS, q[:, 0], q[:, 1], q[:, 2], q[:, 3].astype(np.int32),
+                                        q[:, 4].astype(np.int32))
+    for (args, want), got in zip(queries, lists):
+        assert list(got) == want, args
+    for (c, r), items in cells.items():
+        assert list(ci[cs[c * 48 + r]:cs[c * 48 + r + 1]]) == items
+    assert cs[-1] == 8
+    k1, d1, k2, d2, win, ratio, no_ori, with_ori = K.search_for_initialization_case()
+    for ori, (want_n, want_m) in ((False, no_ori), (True, with_ori)):
+        mt = orbx.ORBmatcher(ratio, ori)
+        prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1), np.float32)
+        before = prev.copy()
+        n, m12, pairs = mt.SearchForInitialization(k1, d1, k2, d2, K.BOUNDS, prev, win)
+        assert n == want_n and list(m12) == want_m and pairs == 15
+        for i, j in enumerate(want_m):
+            assert tuple(prev[i]) == ((k2["x"][j], k2["y"][j]) if j >= 0 else tuple(before[i]))
+        # device batch form: the two frames as a batch of two in the extractor's result layout
+        cap = 16
+        kp = np.zeros((2, cap), L.KEYPOINT_DTYPE)
+        de = np.zeros((2, cap, 32), np.uint8)
+        kp[0, :len(k1)], kp[1, :len(k2)] = k1, k2
+        de[0, :len(k1)], de[1, :len(k2)] = d1, d2
+        d_kp = torch.from_numpy(kp.view(np.uint8).reshape(2, -1)).cuda()
+        d_de = torch.from_numpy(de).cuda()
+        d_cnt = torch.tensor([len(k1), len(k2)], dtype=torch.int32, device="cuda")
+        o12 = torch.full((1, cap), -7, dtype=torch.int32, device="cuda")
+        onm = torch.zeros(1, dtype=torch.int32, device="cuda")
+        onp = torch.zeros(1, dtype=torch.int32, device="cuda")
+        pout = torch.full((1, cap, 2), -1.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        mt.set_stream(torch.cuda.current_stream().cuda_stream)
+        mt.search_for_initialization_batch_device(d_kp.data_ptr(), d_de.data_ptr(), d_cnt.data_ptr(), cap, 2, 16,
+                                                  K.BOUNDS, o12.data_ptr(), onm.data_ptr(), onp.data_ptr(),
+                                                  windowSize=win, d_prev_matched_out=pout.data_ptr())
+        torch.cuda.synchronize()
+        assert int(onm.item()) == want_n and list(o12.cpu().numpy()[0, :len(k1)]) == want_m
+        assert int(onp.item()) == 15
+        po = pout.cpu().numpy()[0]
+        for i, j in enumerate(want_m):
+            if j >= 0:
+                assert tuple(po[i]) == (k2["x"][j], k2["y"][j])

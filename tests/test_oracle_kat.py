@@ -601,3 +601,40 @@ def test_brief_rounds_half_to_even(oracle):
     got = oracle.brief_descriptor(img, 20, 20, 30.0)
     assert np.array_equal(got, even)
     assert not np.array_equal(even, away)
+
+
+def test_features_in_area_hand_case(oracle):
+    """Frame::PosInGrid / GetFeaturesInArea (src/Frame.cc:349-420) against a case worked out on paper
+    (tests/kat_cases.py): round-to-nearest binning, keypoints that fall off the grid's last half cell, the
+    column-outer / row-inner visiting order, strict radius, level switches, the four early returns."""
+    import kat_cases as K
+    kps, cells, queries = K.features_in_area_case()
+    q = np.array([a for a, _ in queries], np.float32)
+    lists, cs, ci = oracle.grid_queries(kps, K.BOUNDS, q[:, 0], q[:, 1], q[:, 2], q[:, 3].astype(np.int32),
+                                        q[:, 4].astype(np.int32))
+    for (args, want), got in zip(queries, lists):
+        assert list(got) == want, args
+    # the grid itself: cell = column * 48 + row, items in index order
+    for c in range(64):
+        for r in range(48):
+            items = list(ci[cs[c * 48 + r]:cs[c * 48 + r + 1]])
+            assert items == cells.get((c, r), []), (c, r)
+    assert cs[-1] == 8  # keypoints 6 and 8 are in no cell
+
+
+def test_search_for_initialization_hand_case(oracle):
+    """ORBmatcher::SearchForInitialization (src/ORBmatcher.cc:433-549) against a case worked out on paper
+    (tests/kat_cases.py): a match taken over by a later keypoint, a candidate skipped by vMatchedDistance, a
+    level-1 keypoint ignored, a second-best of INT_MAX passing the ratio, TH_LOW, a ratio failure, and a match
+    cleared by the three-maxima histogram in which a taken-over entry still counts."""
+    import kat_cases as K
+    k1, d1, k2, d2, win, ratio, no_ori, with_ori = K.search_for_initialization_case()
+    for ori, (want_n, want_m) in ((0, no_ori), (1, with_ori)):
+        prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1), np.float32)
+        before = prev.copy()
+        n, m12, pairs = oracle.search_for_initialization(k1, d1, k2, d2, K.BOUNDS, prev, win, ratio, ori)
+        assert n == want_n and list(m12) == want_m
+        assert pairs == 2 + 2 + 2 + 1 + 2 + 6  # i0, i1, i2: j0 and j1; i4: j2; i5: j3 and j4; six isolated pairs
+        for i, j in enumerate(want_m):
+            want_xy = (k2["x"][j], k2["y"][j]) if j >= 0 else tuple(before[i])
+            assert tuple(prev[i]) == want_xy, i
