@@ -403,6 +403,35 @@ int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const float *angle
                        const int32_t *node_start2, const int32_t *node_items2, int m2, int strict_lt, float nnratio,
                        int check_orientation, int32_t *match12, int32_t *match21, int32_t *nmatches);
 
+/* The same two searches for frames that stay in device memory: both sides in the layout of
+ * orbx_batch_device_results (key frame b of side 1 at rows b*max_keypoints1 .., d_counts1[b] of them valid; side 2
+ * is one frame of up to max_keypoints2 rows), angles read from the keypoint records (mvKeysUn[i].angle,
+ * src/ORBmatcher.cc:252, :651), feature vectors as orbx_feature_vectors_build_device writes them.  valid1 /
+ * valid2: one byte per row as above or NULL.  d_match12: nb x max_keypoints1 (index into side 2 or -1),
+ * d_match21: nb x max_keypoints2 (feature of the key frame or -1), d_nmatches[nb]: matches of the key frame, or
+ * ORBX_E_CAPACITY when one of its nodes holds more than 4096 features of side 2.  Device pointers; asynchronous
+ * on the matcher's stream; no copy to or from the host. */
+int orbx_search_by_bow_device(orbx_matcher *m, const orbx_keypoint *d_keypoints1, const uint8_t *d_desc1,
+                              const int32_t *d_counts1, const uint8_t *d_valid1, int nb, int max_keypoints1,
+                              const int32_t *d_node_ids1, const int32_t *d_node_start1, const int32_t *d_node_items1,
+                              const orbx_keypoint *d_keypoints2, const uint8_t *d_desc2, const uint8_t *d_valid2,
+                              int max_keypoints2, const int32_t *d_node_ids2, const int32_t *d_node_start2,
+                              const int32_t *d_node_items2, int strict_lt, float nnratio, int check_orientation,
+                              int32_t *d_match12, int32_t *d_match21, int32_t *d_nmatches);
+/* DBoW2::FeatureVector of nframes device-resident frames from the per-feature node ids that
+ * orbx_vocabulary_transform_device produced (the fv half of TemplatedVocabulary::transform,
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1145-1193, FeatureVector::addFeature,
+ * Thirdparty/DBoW2/DBoW2/FeatureVector.cpp:31-45; Frame::ComputeBoW, src/Frame.cc:422-431).  d_node: nframes x
+ * max_keypoints node ids, frame f's first d_counts[f] rows valid; a negative id leaves the feature out (a word
+ * of weight 0 is not added, :1157).  Per frame f: d_node_ids + f*max_keypoints receives the distinct node ids in
+ * ascending order (the map's order), padded with INT32_MAX; d_node_start + f*(max_keypoints+1) the offset of each
+ * entry's features in d_node_items + f*max_keypoints (feature indices local to the frame, ascending inside an
+ * entry; padding entries are empty); d_num_nodes[f] the number of entries.  max_keypoints <= 8192.  Device
+ * pointers; asynchronous on the matcher's stream. */
+int orbx_feature_vectors_build_device(orbx_matcher *m, const int32_t *d_node, const int32_t *d_counts, int nframes,
+                                      int max_keypoints, int32_t *d_node_ids, int32_t *d_node_start,
+                                      int32_t *d_node_items, int32_t *d_num_nodes);
+
 /* ---------------------------------------------------------------- vocabulary */
 
 /* The descriptor -> word quantisation of DBoW2: TemplatedVocabulary<FORB::TDescriptor, FORB>::transform

@@ -110,6 +110,9 @@ SIGNATURES = {
     "orbx_undistort_points": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "orbx_search_by_bow": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P,
                                      C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P]),
+    "orbx_search_by_bow_device": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P,
+                                            _P, C.c_int, C.c_float, C.c_int, _P, _P, _P]),
+    "orbx_feature_vectors_build_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P]),
     "orbx_vocabulary_create": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     "orbx_vocabulary_destroy": (None, [_P]),
     "orbx_vocabulary_transform_device": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, _P, _P]),

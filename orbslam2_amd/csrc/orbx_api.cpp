@@ -2189,6 +2189,55 @@ extern "C" int orbx_search_by_bow(orbx_matcher *m, const uint8_t *desc1, const f
     return status ? ORBX_E_CAPACITY : ORBX_OK;
 }
 
+extern "C" int orbx_feature_vectors_build_device(orbx_matcher *m, const int32_t *d_node, const int32_t *d_counts,
+                                                 int nframes, int max_keypoints, int32_t *d_node_ids,
+                                                 int32_t *d_node_start, int32_t *d_node_items, int32_t *d_num_nodes)
+{
+    if (!m || !d_node || !d_counts || nframes < 1 || max_keypoints < 1 || !d_node_ids || !d_node_start || !d_node_items ||
+        !d_num_nodes)
+        return ORBX_E_ARG;
+    if (max_keypoints > 8192)
+        return ORBX_E_CAPACITY;  // the sort keeps a frame's keys (8 bytes each) in 64 KB of LDS
+    HIP_TRY(hipSetDevice(m->device));
+    int rc = grow(&m->d_seg, &m->seg_cap, (size_t)nframes * max_keypoints, m->stream);  // nodes in sorted order
+    if (rc != ORBX_OK)
+        return rc;
+    HIP_TRY(orbx_launch_feature_vectors(d_node, d_counts, nframes, max_keypoints, m->d_seg, d_node_ids, d_node_start,
+                                        d_node_items, d_num_nodes, m->stream));
+    return ORBX_OK;
+}
+
+extern "C" int orbx_search_by_bow_device(orbx_matcher *m, const orbx_keypoint *d_keypoints1, const uint8_t *d_desc1,
+                                         const int32_t *d_counts1, const uint8_t *d_valid1, int nb, int max_keypoints1,
+                                         const int32_t *d_node_ids1, const int32_t *d_node_start1,
+                                         const int32_t *d_node_items1, const orbx_keypoint *d_keypoints2,
+                                         const uint8_t *d_desc2, const uint8_t *d_valid2, int max_keypoints2,
+                                         const int32_t *d_node_ids2, const int32_t *d_node_start2,
+                                         const int32_t *d_node_items2, int strict_lt, float nnratio,
+                                         int check_orientation, int32_t *d_match12, int32_t *d_match21,
+                                         int32_t *d_nmatches)
+{
+    if (!m || !d_keypoints1 || !d_desc1 || !d_counts1 || nb < 1 || max_keypoints1 < 1 || !d_node_ids1 || !d_node_start1 ||
+        !d_node_items1 || !d_keypoints2 || !d_desc2 || max_keypoints2 < 1 || !d_node_ids2 || !d_node_start2 ||
+        !d_node_items2 || !d_match12 || !d_match21 || !d_nmatches)
+        return ORBX_E_ARG;
+    if (max_keypoints2 > 65535 || (int64_t)nb * max_keypoints1 > INT32_MAX / 2)
+        return ORBX_E_CAPACITY;  // list positions travel in 16 bits of the wave's keys
+    HIP_TRY(hipSetDevice(m->device));
+    // workspace: rotation bin per feature of side 1, then histograms, per-key-frame status, one status word
+    const size_t bins = ((size_t)nb * max_keypoints1 + 255) / 256 * 256;
+    int rc = grow(&m->d_ws, &m->ws_cap, bins + sizeof(int) * (33 * (size_t)nb + 1), m->stream);
+    if (rc != ORBX_OK)
+        return rc;
+    int *hist = reinterpret_cast<int *>(m->d_ws + bins);
+    HIP_TRY(orbx_launch_bow_strided(d_keypoints1, d_desc1, d_counts1, d_valid1, nb, max_keypoints1, d_node_ids1,
+                                    d_node_start1, d_node_items1, d_keypoints2, d_desc2, d_valid2, max_keypoints2,
+                                    d_node_ids2, d_node_start2, d_node_items2, strict_lt, nnratio, check_orientation,
+                                    d_match12, d_match21, d_nmatches, reinterpret_cast<int8_t *>(m->d_ws), hist,
+                                    hist + 32 * (size_t)nb, hist + 33 * (size_t)nb, m->stream));
+    return ORBX_OK;
+}
+
 extern "C" int orbx_distinctive_descriptors_device(orbx_matcher *m, const uint8_t *d_descriptors,
                                                    const int32_t *d_seg_start, int npoints, int32_t *d_best_idx,
                                                    uint8_t *d_best_desc)

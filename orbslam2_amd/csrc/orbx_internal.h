@@ -207,6 +207,15 @@ hipError_t orbx_launch_bow(const uint8_t *d_desc1, const float *d_ang1, const ui
                            const uint8_t *d_valid2, int n2, const int *d_ids2, const int *d_start2, const int *d_items2,
                            int m2, int strict_lt, float ratio, int check_ori, int *d_match12, int *d_match21,
                            int *d_nmatches, int8_t *d_bin_of, int *d_hist, int *d_status, hipStream_t s);
+hipError_t orbx_launch_bow_strided(const orbx_keypoint *d_kp1, const uint8_t *d_desc1, const int *d_counts1,
+                                   const uint8_t *d_valid1, int nb, int cap1, const int *d_ids1, const int *d_start1,
+                                   const int *d_items1, const orbx_keypoint *d_kp2, const uint8_t *d_desc2,
+                                   const uint8_t *d_valid2, int cap2, const int *d_ids2, const int *d_start2,
+                                   const int *d_items2, int strict_lt, float ratio, int check_ori, int *d_match12,
+                                   int *d_match21, int *d_nmatches, int8_t *d_bin_of, int *d_hist, int *d_kf_status,
+                                   int *d_status, hipStream_t s);
+hipError_t orbx_launch_feature_vectors(const int *d_node, const int *d_counts, int nframes, int cap, int *d_sorted,
+                                       int *d_ids, int *d_start, int *d_items, int *d_num, hipStream_t s);
 hipError_t orbx_launch_grid_build(const orbx_keypoint *d_kp, int n, float min_x, float max_x, float min_y, float max_y,
                                   uint32_t *d_keys, int32_t *d_cell_start, int32_t *d_cell_items, hipStream_t s);
 hipError_t orbx_launch_features_in_area(const orbx_keypoint *d_kp, float min_x, float max_x, float min_y, float max_y,

@@ -203,6 +203,30 @@ class ORBmatcher:
         per_kf = [m12[feat_start[b]:feat_start[b + 1]].copy() for b in range(nb)]
         return nm[:nb].copy(), per_kf, m21[:nb, :n2].copy()
 
+    def feature_vectors_build_device(self, d_node, d_counts, nframes, max_keypoints, d_node_ids, d_node_start,
+                                     d_node_items, d_num_nodes):
+        """DBoW2::FeatureVector of device-resident frames (orbx_feature_vectors_build_device in include/orbx.h);
+        device addresses (ints); asynchronous on the matcher's stream."""
+        P = C.c_void_p
+        L.check(self._lib.orbx_feature_vectors_build_device(self._handle(), P(d_node), P(d_counts), nframes,
+                                                            max_keypoints, P(d_node_ids), P(d_node_start),
+                                                            P(d_node_items), P(d_num_nodes)),
+                "orbx_feature_vectors_build_device")
+
+    def search_by_bow_device(self, side1, nb, max_keypoints1, side2, max_keypoints2, d_match12, d_match21, d_nmatches,
+                             strict_lt=False):
+        """ORBmatcher::SearchByBoW on device-resident frames (orbx_search_by_bow_device in include/orbx.h).
+        side1 = (d_keypoints, d_desc, d_counts, d_valid or 0, d_node_ids, d_node_start, d_node_items),
+        side2 = (d_keypoints, d_desc, d_valid or 0, d_node_ids, d_node_start, d_node_items): device addresses."""
+        P = lambda v: C.c_void_p(v) if v else None  # noqa: E731
+        k1, de1, c1, v1, i1, s1, t1 = side1
+        k2, de2, v2, i2, s2, t2 = side2
+        L.check(self._lib.orbx_search_by_bow_device(self._handle(), P(k1), P(de1), P(c1), P(v1), nb, max_keypoints1,
+                                                    P(i1), P(s1), P(t1), P(k2), P(de2), P(v2), max_keypoints2, P(i2),
+                                                    P(s2), P(t2), int(strict_lt), self.mfNNratio,
+                                                    int(self.mbCheckOrientation), P(d_match12), P(d_match21),
+                                                    P(d_nmatches)), "orbx_search_by_bow_device")
+
     def search_by_projection(self, keypoints, descriptors, bounds, x, y, r, min_level, max_level, src_desc, *,
                              uright=None, taken=None, valid=None, xr=None, blocks=None, src_angle=None,
                              use_second=True, th_dist=100, check_orientation=False):

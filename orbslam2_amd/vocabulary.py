@@ -43,6 +43,13 @@ class ORBVocabulary:
                                                     L.ptr(wt)), "orbx_vocabulary_transform")
         return word[:n], node[:n], wt[:n]
 
+    def transform_features_device(self, d_descriptors, n, d_word, d_node, d_weight, levelsup=4, stream=0):
+        """The same for n descriptors in device memory; all pointers are device addresses (ints), outputs
+        int32 / int32 / float64 arrays of n entries.  Asynchronous on `stream` (a hipStream_t, 0 = default)."""
+        P = C.c_void_p
+        L.check(self._lib.orbx_vocabulary_transform_device(self._h, P(stream), P(d_descriptors), n, levelsup, P(d_word),
+                                                           P(d_node), P(d_weight)), "orbx_vocabulary_transform_device")
+
     def transform(self, descriptors, levelsup=4):
         """Frame::ComputeBoW (src/Frame.cc:422-431): (BowVector as {word: value}, FeatureVector as
         {node: [feature indices]}) for TF_IDF weighting and L1 scoring, the configuration of ORBvoc

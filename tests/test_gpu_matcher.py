@@ -753,3 +753,107 @@ def test_hand_worked_cases_through_the_hip_path():
         for i, j in enumerate(want_m):
             if j >= 0:
                 assert tuple(po[i]) == (k2["x"][j], k2["y"][j])
+
+
+@pytest.mark.parametrize("strict,ratio,ori", [(False, 0.75, True), (True, 0.8, True), (False, 0.7, False)])
+def test_search_by_bow_device_chain_vs_oracle(oracle, strict, ratio, ori):
+    """Relocalisation-style chain without a host hop: descriptors in device memory -> vocabulary transform ->
+    feature vectors (sort by node id) -> SearchByBoW, all through device-pointer entry points; against the
+    oracle's transform, a numpy FeatureVector (ascending node ids, features in index order) and the oracle's
+    SearchByBoW per key frame."""
+    import torch
+    from orbslam2_amd import _lib as L
+    rng = np.random.default_rng(77 + int(strict))
+    tree = _random_tree(rng, 8, 5, early_leaf=0.05)
+    voc = orbx.ORBVocabulary(tree["desc"], tree["child_start"], tree["children"], tree["word_id"], tree["weight"],
+                             tree["L"])
+    nb, cap1, cap2, n2 = 5, 700, 1600, 1500
+    leaves = np.flatnonzero(tree["word_id"] >= 0)
+    d2 = tree["desc"][rng.choice(leaves, size=n2)].copy()
+    d2[:, 5:17] ^= rng.integers(0, 256, size=(n2, 12), dtype=np.uint8)    # near a leaf, so nodes are shared
+    d2[:400] = tree["desc"][leaves[3]]                                      # one crowded node
+    d2[:400, 20:] = rng.integers(0, 256, size=(400, 12), dtype=np.uint8)
+    counts1 = np.array([700, 0, 333, 1, 650], np.int32)
+    kp1 = np.zeros((nb, cap1), L.KEYPOINT_DTYPE)
+    de1 = rng.integers(0, 256, size=(nb, cap1, 32), dtype=np.uint8)         # rows past the count: garbage
+    kp1["angle"] = (rng.random((nb, cap1)) * 360).astype(np.float32)
+    kp2 = np.zeros(cap2, L.KEYPOINT_DTYPE)
+    kp2["angle"] = (rng.random(cap2) * 360).astype(np.float32)
+    for b in range(nb):
+        pick = rng.integers(0, n2, size=counts1[b])
+        rows = d2[pick].copy()
+        rows[:, 28:] ^= rng.integers(0, 4, size=(counts1[b], 4), dtype=np.uint8)
+        fresh = rng.random(counts1[b]) < 0.15
+        rows[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), 32), dtype=np.uint8)
+        de1[b, :counts1[b]] = rows
+        # a key frame is the frame seen rotated by 30 degrees, give or take: most matches share a few rotation bins
+        kp1["angle"][b, :counts1[b]] = (kp2["angle"][pick] + 30 + rng.normal(0, 6, size=counts1[b])) % 360
+    de2 = rng.integers(0, 256, size=(cap2, 32), dtype=np.uint8)
+    de2[:n2] = d2
+    valid1 = (rng.random((nb, cap1)) < 0.85).astype(np.uint8)
+    valid2 = (rng.random(cap2) < 0.9).astype(np.uint8) if strict else None
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()  # noqa: E731
+    t_kp1, t_de1, t_c1, t_v1 = dev(kp1), dev(de1), dev(counts1), dev(valid1)
+    t_kp2, t_de2, t_c2 = dev(kp2), dev(de2), dev(np.array([n2], np.int32))
+    t_v2 = dev(valid2) if valid2 is not None else None
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")  # noqa: E731
+    word1, node1, word2, node2 = i32(nb * cap1), i32(nb * cap1), i32(cap2), i32(cap2)
+    wt1 = torch.zeros(nb * cap1, dtype=torch.float64, device="cuda")
+    wt2 = torch.zeros(cap2, dtype=torch.float64, device="cuda")
+    m = orbx.ORBmatcher(ratio, ori)
+    st = torch.cuda.current_stream().cuda_stream
+    m.set_stream(st)
+    voc.transform_features_device(t_de1.data_ptr(), nb * cap1, word1.data_ptr(), node1.data_ptr(), wt1.data_ptr(),
+                                  levelsup=2, stream=st)
+    voc.transform_features_device(t_de2.data_ptr(), cap2, word2.data_ptr(), node2.data_ptr(), wt2.data_ptr(),
+                                  levelsup=2, stream=st)
+    node1 = torch.where(wt1 > 0, node1, torch.full_like(node1, -1))   # a word of weight 0 is in no node
+    node2 = torch.where(wt2 > 0, node2, torch.full_like(node2, -1))
+    ids1, start1, items1, num1 = i32(nb * cap1), i32(nb * (cap1 + 1)), i32(nb * cap1), i32(nb)
+    ids2, start2, items2, num2 = i32(cap2), i32(cap2 + 1), i32(cap2), i32(1)
+    m.feature_vectors_build_device(node1.data_ptr(), t_c1.data_ptr(), nb, cap1, ids1.data_ptr(), start1.data_ptr(),
+                                   items1.data_ptr(), num1.data_ptr())
+    m.feature_vectors_build_device(node2.data_ptr(), t_c2.data_ptr(), 1, cap2, ids2.data_ptr(), start2.data_ptr(),
+                                   items2.data_ptr(), num2.data_ptr())
+    m12, m21, nm = i32(nb * cap1), i32(nb * cap2), i32(nb)
+    m.search_by_bow_device((t_kp1.data_ptr(), t_de1.data_ptr(), t_c1.data_ptr(), t_v1.data_ptr(), ids1.data_ptr(),
+                            start1.data_ptr(), items1.data_ptr()), nb, cap1,
+                           (t_kp2.data_ptr(), t_de2.data_ptr(), t_v2.data_ptr() if t_v2 is not None else 0,
+                            ids2.data_ptr(), start2.data_ptr(), items2.data_ptr()), cap2,
+                           m12.data_ptr(), m21.data_ptr(), nm.data_ptr(), strict_lt=strict)
+    torch.cuda.synchronize()
+    # expected: oracle transform, numpy feature vectors, oracle search per key frame
+    def fv_of(desc):
+        _, node, wt = oracle.vocabulary_transform(tree, desc, 2)
+        keep = np.flatnonzero(wt > 0)
+        ids, start, order = _feature_vector(node[keep])
+        return ids, start, keep[order].astype(np.int32)
+    e_ids2, e_start2, e_items2 = fv_of(d2)
+    E2 = int(num2.item())
+    assert E2 == len(e_ids2)
+    assert np.array_equal(ids2.cpu().numpy()[:E2], e_ids2) and (ids2.cpu().numpy()[E2:] == 0x7fffffff).all()
+    assert np.array_equal(start2.cpu().numpy()[:E2 + 1], e_start2) and (start2.cpu().numpy()[E2:] == e_start2[-1]).all()
+    assert np.array_equal(items2.cpu().numpy()[:e_start2[-1]], e_items2)
+    h12, h21, hn = m12.cpu().numpy().reshape(nb, cap1), m21.cpu().numpy().reshape(nb, cap2), nm.cpu().numpy()
+    hid1, hst1, hit1 = (ids1.cpu().numpy().reshape(nb, cap1), start1.cpu().numpy().reshape(nb, cap1 + 1),
+                        items1.cpu().numpy().reshape(nb, cap1))
+    total = 0
+    for b in range(nb):
+        n1 = int(counts1[b])
+        f_ids, f_start, f_items = fv_of(de1[b, :n1]) if n1 else (np.zeros(0, np.int32), np.zeros(1, np.int32),
+                                                                 np.zeros(0, np.int32))
+        E1 = int(num1.cpu().numpy()[b])
+        assert E1 == len(f_ids) and np.array_equal(hid1[b, :E1], f_ids) and np.array_equal(hst1[b, :E1 + 1], f_start)
+        assert np.array_equal(hit1[b, :f_start[-1]], f_items)
+        if n1 == 0:
+            assert hn[b] == 0 and (h21[b] == -1).all()
+            continue
+        en, e12, e21 = oracle.search_by_bow(de1[b, :n1], kp1["angle"][b, :n1], valid1[b, :n1], (f_ids, f_start, f_items),
+                                            d2, kp2["angle"][:n2], None if valid2 is None else valid2[:n2],
+                                            (e_ids2, e_start2, e_items2), strict, ratio, ori)
+        assert hn[b] == en, b
+        assert np.array_equal(h12[b, :n1], e12) and (h12[b, n1:] == -1).all()
+        assert np.array_equal(h21[b, :n2], e21) and (h21[b, n2:] == -1).all()
+        total += en
+    assert total > 200  # (the orientation check and the valid flags thin the matches out)
+    voc.close()
