@@ -8,28 +8,17 @@
 // ---------------------------------------------------------------- blur
 
 struct BlurArgs {
-    int nlevels, slab, bslab, variant, batch;
+    int nlevels, slab, bslab, variant, batch, tiles_per_frame;
     OrbxLevel0 l0;
     int w[ORBX_MAX_LEVELS], h[ORBX_MAX_LEVELS], pitch[ORBX_MAX_LEVELS], off[ORBX_MAX_LEVELS], boff[ORBX_MAX_LEVELS];
 };
 
-__device__ __forceinline__ int reflect101(int i, int n)
-{
-    // BORDER_REFLECT_101: ... 2 1 | 0 1 2 ... n-2 n-1 | n-2 n-3 ...
-    if (n == 1)
-        return 0;
-    while (i < 0 || i >= n)
-        i = i < 0 ? -i : 2 * (n - 1) - i;
-    return i;
-}
+#include "blur_stage.h"
 
-#define BL_W ORBX_FT_W          // 128 output columns per tile
-#define BL_H ORBX_FT_H          // 32 output rows per tile
-#define BL_LEFT 16              // staged columns start at tx0-16 (16-byte aligned); 3 are needed
-#define BL_SWORDS 40            // staged words per row: columns tx0-16 .. tx0+143
-#define BL_SH (BL_H + 6)        // staged rows ty0-3 .. ty0+34 (38 rows = 19 row pairs)
-#define BL_PAIRS (BL_SH / 2)
-#define BL_GROUPS (BL_W / 4)    // 4-pixel groups per row
+#ifndef BLUR_TPW
+#define BLUR_TPW 1  // tiles per workgroup (4, with the next tile's pieces fetched ahead, shortens the kernel alone by
+                    // 2 % and costs a batch 2.7 % of its frames/s: fewer, longer workgroups interleave worse)
+#endif
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
@@ -51,18 +40,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 {
     __shared__ __attribute__((aligned(16))) uint32_t img[BL_SH * BL_SWORDS];
     __shared__ __attribute__((aligned(16))) uint32_t hs[BL_PAIRS * BL_W];  // h(row 2p, x) | h(row 2p+1, x) << 16
-    const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
+    const int f = ORBX_BLOCK_FRAME;
     if (f >= a.batch)
         return;
-    // the tile's level, row and column from the host's table: one scalar load instead of a search over the
-    // levels and a division in every wave (scalar instructions are issued at the rate of the slower vector ones)
-    const uint32_t te = tile_tab[unit];
-    const int lvl = te >> 24;
-    const int tx0 = (int)(te & 0xfffu) * BL_W, ty0 = (int)((te >> 12) & 0xfffu) * BL_H;
-    const int w = a.w[lvl], h = a.h[lvl], pitch = a.pitch[lvl];
-    const int spitch = lvl == 0 ? a.l0.pitch : pitch;
-    const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
-    uint8_t *dst = blur + (size_t)f * a.bslab + a.boff[lvl];  // tiled: ORBX_BLUR_ADDR
     const uint32_t k0 = 18, k1 = 34, k2 = VARIANT ? 49 : 48, k3 = VARIANT ? 55 : 56;
     // the seven taps k0 k1 k2 k3 k2 k1 k0 laid over bytes o+1 .. o+7 of three words, for o = 0 .. 3
     const uint32_t t0a = (k0 << 8) | (k1 << 16) | (k2 << 24), t0b = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
@@ -70,90 +50,38 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const uint32_t t2a = k0 << 24, t2b = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), t2c = k1 | (k0 << 8);
     const uint32_t t3b = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), t3c = k2 | (k1 << 8) | (k0 << 16);
 
-    // Staging in whole 16-byte pieces wherever the level is 16-byte aligned.  interior: every needed pixel (3
-    // around the tile) exists.  Other tiles mirror the rows outside the image (reflect 101: a staged row is a
-    // source row, the same for the whole row), skip the pieces left of column 0 or behind the row pitch, and
-    // afterwards patch the three columns left of the image and the three right of it byte by byte.  Nearly half
-    // of the tiles of a pyramid touch a border, so they must not cost more than this.
-    // a tile at the bottom of a level holds h - ty0 < 32 rows: only the row pairs those rows read are staged and filtered
-    const int npairs = min(BL_PAIRS, (h - ty0 + 7) >> 1);
-    const bool aligned = (spitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
-    const bool interior = aligned && tx0 >= BL_LEFT && tx0 + BL_W + 3 <= w && tx0 + BL_W + 16 <= spitch && ty0 >= 3 &&
-                          ty0 + BL_H + 3 <= h;
-    if (aligned) {
-        // readable bytes of the level: a caller's level-0 buffer may end with the last row's pixels
-        const uint32_t src_bytes = (uint32_t)spitch * (uint32_t)(h - 1) + (uint32_t)(lvl == 0 ? w : spitch);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = threadIdx.x + 256 * k;  // 38 rows x 10 pieces = 380 items
-            if (i < 2 * npairs * (BL_SWORDS / 4)) {
-                const int r = i / (BL_SWORDS / 4), c = i % (BL_SWORDS / 4);
-                const int x0 = tx0 - BL_LEFT + 16 * c;
-                const int sy = interior ? ty0 - 3 + r : reflect101(ty0 - 3 + r, h);
-                if (interior || (x0 >= 0 && x0 + 16 <= spitch)) {
-                    const uint32_t o = (uint32_t)(__umul24(sy, spitch) + x0);
-                    uint4 v;
-                    if (interior || o + 16u <= src_bytes) {
-                        v = *reinterpret_cast<const uint4 *>(src + o);
-                    } else {
-                        // the last pieces of the last row: pixels only
-                        uint32_t q[4] = {0, 0, 0, 0};
-                        for (int b = 0; b < 16; b++)
-                            if (x0 + b < w)
-                                q[b >> 2] |= (uint32_t)src[o + b] << (8 * (b & 3));
-                        v = make_uint4(q[0], q[1], q[2], q[3]);
-                    }
-                    *reinterpret_cast<uint4 *>(&img[r * BL_SWORDS + 4 * c]) = v;
-                }
-            }
-        }
-        if (!interior) {
-            __syncthreads();
-            if (threadIdx.x < BL_SH * 6) {
-                const int r = threadIdx.x / 6, k = threadIdx.x % 6;
-                const int x = k < 3 ? -1 - k : w + k - 3;
-                const int col = x - (tx0 - BL_LEFT);  // staged byte column
-                if (col >= 0 && col < 4 * BL_SWORDS)
-                    reinterpret_cast<uint8_t *>(img)[r * (4 * BL_SWORDS) + col] =
-                        src[(uint32_t)__umul24(reflect101(ty0 - 3 + r, h), spitch) + reflect101(x, w)];
-            }
-        }
-    } else {
-        // unaligned level (a caller's level 0 at an odd address or pitch): rows and columns outside the image
-        // mirror about the border pixel; words that lie inside the row are still loaded whole.  Only words 3 .. 36 of a staged row
-        // (columns tx0-4 .. tx0+131) are needed.  A thread keeps one word column, so the column's
-        // reflected byte offsets are computed once, and walks down the rows.
-        const int c4 = threadIdx.x & 63;
-        if (c4 < 34) {
-            const int x0 = tx0 - 4 + c4 * 4;
-            const bool whole = x0 >= 0 && x0 + 3 < w;
-            const bool unused = x0 >= w + 3;  // right of every needed column
-            const int o0 = whole ? x0 : reflect101(x0, w), o1 = reflect101(x0 + 1, w);
-            const int o2 = reflect101(x0 + 2, w), o3 = reflect101(x0 + 3, w);
-            // all loads of the thread's rows are issued before the first store
-            uint32_t v[(BL_SH + 3) / 4];
-#pragma unroll
-            for (int k = 0; k < (BL_SH + 3) / 4; k++) {
-                const int r = (threadIdx.x >> 6) + 4 * k;
-                v[k] = 0;
-                if (r < BL_SH && !unused) {
-                    const uint8_t *row = src + (uint32_t)__umul24(reflect101(ty0 - 3 + r, h), spitch);
-                    if (whole)
-                        v[k] = *reinterpret_cast<const uint32_t *>(row + o0);
-                    else
-                        v[k] = (uint32_t)row[o0] | ((uint32_t)row[o1] << 8) | ((uint32_t)row[o2] << 16) |
-                               ((uint32_t)row[o3] << 24);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < (BL_SH + 3) / 4; k++) {
-                const int r = (threadIdx.x >> 6) + 4 * k;
-                if (r < BL_SH)
-                    img[r * BL_SWORDS + 3 + c4] = v[k];
-            }
-        }
-    }
+    // A workgroup takes BLUR_TPW tiles in turn.  The level, row and column of a tile come from the host's table
+    // (one scalar load instead of a search over the levels and a division in every wave: scalar instructions are
+    // issued at the rate of the slower vector ones).  The next tile's pieces are fetched into registers while the
+    // current one is filtered: with one tile's loads in flight per workgroup the bytes in flight per compute unit
+    // do not cover the memory latency.
+    const int unit0 = ORBX_BLOCK_UNIT * BLUR_TPW;
+    const int nunits = min(BLUR_TPW, a.tiles_per_frame - unit0);
+    auto tile_of = [&](int unit, int &lvl) -> BlurTile {
+        const uint32_t te = tile_tab[unit];
+        lvl = te >> 24;
+        const int spitch = lvl == 0 ? a.l0.pitch : a.pitch[lvl];
+        const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
+        return BlurTile{src, spitch, a.w[lvl], a.h[lvl], (int)(te & 0xfffu) * BL_W, (int)((te >> 12) & 0xfffu) * BL_H,
+                        lvl == 0};
+    };
+    int lvl_next = 0;
+    BlurTile next = tile_of(unit0, lvl_next);
+    BlurFetch fx;
+    blur_stage_fetch(next, fx);
+    for (int tile = 0; tile < nunits; tile++) {
+    const BlurTile cur = next;
+    const int lvl = lvl_next;
+    const int tx0 = cur.tx0, ty0 = cur.ty0, h = cur.h, pitch = a.pitch[lvl];
+    uint8_t *dst = blur + (size_t)f * a.bslab + a.boff[lvl];  // tiled: ORBX_BLUR_ADDR
+    const int npairs = cur.npairs();
+    // (every wave has left the previous tile's horizontal pass, the last reader of img, at the barrier behind it)
+    blur_stage_commit(img, cur, fx);
     __syncthreads();
+    if (tile + 1 < nunits) {
+        next = tile_of(unit0 + tile + 1, lvl_next);
+        blur_stage_fetch(next, fx);
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int item = threadIdx.x + 256 * k;  // 19 row pairs x 32 groups = 608 items
@@ -228,21 +156,24 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         }
         *reinterpret_cast<uint4 *>(dst + (uint32_t)ORBX_BLUR_ADDR(x, y0, pitch)) = make_uint4(out[0], out[1], out[2], out[3]);
     }
+    }  // tiles of the workgroup (the barrier behind the next tile's staging also guards hs)
 }
 
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
 {
     BlurArgs a;
     a.nlevels = g.nlevels, a.slab = g.slab, a.bslab = g.bslab, a.variant = g.blur_variant, a.batch = g.batch;
+    a.tiles_per_frame = g.tiles_per_frame;
     a.l0 = b.l0;
     for (int l = 0; l < g.nlevels; l++) {
         const OrbxLevel &L = g.lv[l];
         a.w[l] = L.w, a.h[l] = L.h, a.pitch[l] = L.pitch, a.off[l] = L.off, a.boff[l] = L.boff;
     }
+    const dim3 grid = orbx_frame_grid((g.tiles_per_frame + BLUR_TPW - 1) / BLUR_TPW, g.batch);
     if (g.blur_variant)
-        k_blur<1><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, b.tile_tab, a);
+        k_blur<1><<<grid, 256, 0, s>>>(b.pyr, b.blur, b.tile_tab, a);
     else
-        k_blur<0><<<orbx_frame_grid(g.tiles_per_frame, g.batch), 256, 0, s>>>(b.pyr, b.blur, b.tile_tab, a);
+        k_blur<0><<<grid, 256, 0, s>>>(b.pyr, b.blur, b.tile_tab, a);
     return hipGetLastError();
 }
 

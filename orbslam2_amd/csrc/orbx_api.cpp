@@ -79,6 +79,8 @@ struct orbx_extractor {
     OrbxYCoef *d_ytab;
     int *d_ptab;
     uint32_t *d_tiletab;
+    uint8_t *d_blur_bands;     // the four constant tap operands of the matrix-core blur
+    bool blur_mfma;            // ORBX_BLUR=mfma: the matrix-core form of the blur (comparison runs)
     int xtab_cap, ytab_cap, ptab_cap, tiletab_cap;
     std::vector<int> h_counts, h_nkept;
     bool profiling;
@@ -319,7 +321,7 @@ static void free_buffers(orbx_extractor *ex)
     OrbxBuffers &b = ex->buf;
     void *ptrs[] = {b.pyr,       b.blur,    b.cell_flag, b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
                     b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n,   ex->d_ptab, ex->d_xtab,
-                    ex->d_ytab,  ex->d_tiletab};
+                    ex->d_ytab,  ex->d_tiletab, ex->d_blur_bands};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -338,6 +340,7 @@ static void free_buffers(orbx_extractor *ex)
     ex->d_ytab = nullptr;
     ex->d_ptab = nullptr;
     ex->d_tiletab = nullptr;
+    ex->d_blur_bands = nullptr;
 }
 
 extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor **out)
@@ -385,6 +388,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     ex->d_ytab = nullptr;
     ex->d_ptab = nullptr;
     ex->d_tiletab = nullptr;
+    ex->d_blur_bands = nullptr;
     scale_tables(ex);
     int rc = build_geometry(ex, p.max_width, p.max_height, p.max_batch, &ex->cap_geom);
     if (rc == ORBX_E_GEOMETRY) {
@@ -449,6 +453,16 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     if (e == hipSuccess) e = dmalloc(&ex->d_ptab, (size_t)ex->ptab_cap);
     ex->tiletab_cap = g.tiles_per_frame + g.ftiles_per_frame;
     if (e == hipSuccess) e = dmalloc(&ex->d_tiletab, (size_t)ex->tiletab_cap);
+    if (e == hipSuccess) e = dmalloc(&ex->d_blur_bands, orbx_blur_mfma_band_bytes());
+    if (e == hipSuccess) {
+        std::vector<uint8_t> bands;
+        orbx_blur_mfma_tables(bands);
+        e = hipMemcpy(ex->d_blur_bands, bands.data(), bands.size(), hipMemcpyHostToDevice);
+    }
+    {
+        const char *mode = getenv("ORBX_BLUR");  // "mfma": the matrix-core kernel (bit-equal, no faster: comparison runs)
+        ex->blur_mfma = mode && strcmp(mode, "mfma") == 0;
+    }
     if (e != hipSuccess) {
         g_last_hip = (int)e;
         free_buffers(ex);
@@ -464,6 +478,7 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     b.ytab = ex->d_ytab;
     b.ptab = ex->d_ptab;
     b.tile_tab = ex->d_tiletab;
+    b.blur_bands = ex->d_blur_bands;
     *out = ex;
     return ORBX_OK;
 }
@@ -613,7 +628,11 @@ static int run_pipeline(orbx_extractor *ex)
         HIP_TRY(hipStreamWaitEvent(s2, ex->ev_pyramid, 0));
     }
     HIP_TRY(prof_mark(ex, 4, 0, s2));
-    HIP_TRY(orbx_launch_blur(g, b, s2));
+    // (the matrix-core form covers the 256-sum taps; the 257-sum variant saturates and has the vector-ALU form only)
+    if (g.blur_variant == 0 && ex->blur_mfma)
+        HIP_TRY(orbx_launch_blur_mfma(g, b, s2));
+    else
+        HIP_TRY(orbx_launch_blur(g, b, s2));
     HIP_TRY(prof_mark(ex, 4, 1, s2));
     if (overlap)
         HIP_TRY(hipEventRecord(ex->ev_blur, s2));

@@ -122,6 +122,7 @@ struct OrbxBuffers {
     // level << 24 | tile row << 12 | tile column of every blur tile of a frame (tiles_per_frame entries), then of
     // every FAST tile (ftiles_per_frame entries): a workgroup finds its tile with one scalar load
     const uint32_t *tile_tab;
+    const uint8_t *blur_bands;  // the four constant tap operands of the matrix-core blur
 };
 #define ORBX_TILE_ENTRY(lvl, ty, tx) (((uint32_t)(lvl) << 24) | ((uint32_t)(ty) << 12) | (uint32_t)(tx))
 
@@ -185,6 +186,13 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
 hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_describe(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+// the blur on the matrix cores (blur_variant 0); its four constant tap operands
+#ifdef __cplusplus
+#include <vector>
+size_t orbx_blur_mfma_band_bytes(void);
+void orbx_blur_mfma_tables(std::vector<uint8_t> &bands);
+hipError_t orbx_launch_blur_mfma(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+#endif
 size_t orbx_octree_lds_bytes(int node_cap);
 
 // standalone quadtree run on caller-provided candidates (parity tests)

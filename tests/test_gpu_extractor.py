@@ -528,3 +528,28 @@ def test_other_image_statistics(oracle, kind):
     if kind in ("board", "field", "bars"):
         assert len(kg) > 300
     ex.close()
+
+
+@pytest.mark.parametrize("w,h", [(1241, 376), (333, 217), (130, 71), (44, 44)])
+def test_matrix_core_blur_equals_oracle(oracle, monkeypatch, w, h):
+    """The opt-in matrix-core form of the 7x7 blur (ORBX_BLUR=mfma, read when a handle is created): every blurred
+    level, borders and partial tiles included, bit-equal to the oracle, and the frame's results with it."""
+    monkeypatch.setenv("ORBX_BLUR", "mfma")
+    p = dict(KITTI)
+    img = orbx.synth_image(SEED + w, w, h, 0)
+    ex = make_extractor(p, w, h)
+    kg, dg = ex(img)
+    ko, do, tr = oracle_extract(oracle, img, p, trace=True)
+    for l in range(p["nlevels"]):
+        if tr["blur"][l] is not None:
+            assert np.array_equal(ex.debug_level_map(1, 0, l), tr["blur"][l]), "blur level %d" % l
+    compare_frame(kg, dg, ko, do)
+    ex.close()
+    # a batch with rows that are not read in place (stride not a multiple of 4 is copied into the pyramid)
+    ex = make_extractor(p, w, h, batch=3)
+    imgs = [orbx.synth_image(SEED + 5 * i, w, h, 0) for i in range(3)]
+    ex.extract_batch_host(imgs)
+    got = ex.batch_download_all()
+    k2, d2 = oracle_extract(oracle, imgs[2], p)
+    compare_frame(got[2][0], got[2][1], k2, d2)
+    ex.close()
