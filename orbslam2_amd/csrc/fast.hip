@@ -194,14 +194,19 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     const int npieces = min(IMG_W / 16, (pitch - (tx0 - IMG_X0)) >> 4);        // pieces 0 .. npieces-1 of a row
     if (aligned) {
         const uint8_t *s0 = src + (size_t)(ty0 - 4) * pitch + (tx0 - IMG_X0);
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = threadIdx.x + 256 * k;  // 72 rows x 6 pieces = 432 items
-            const int r = i / (IMG_W / 16), c = i % (IMG_W / 16);
-            if (r < nrows && c < npieces)
-                *reinterpret_cast<uint4 *>(&img[r * IMG_W + 16 * c]) =
-                    *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(r, pitch) + 16 * c));
-        }
+        // both loads of a thread are in flight before its first LDS store
+        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;  // 72 rows x 6 pieces = 432 items
+        const int ra = i0 / (IMG_W / 16), ca = i0 % (IMG_W / 16), rb = i1 / (IMG_W / 16), cb = i1 % (IMG_W / 16);
+        const bool oka = ra < nrows && ca < npieces, okb = rb < nrows && cb < npieces;
+        uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
+        if (oka)
+            va = *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(ra, pitch) + 16 * ca));
+        if (okb)
+            vb = *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(rb, pitch) + 16 * cb));
+        if (oka)
+            *reinterpret_cast<uint4 *>(&img[ra * IMG_W + 16 * ca]) = va;
+        if (okb)
+            *reinterpret_cast<uint4 *>(&img[rb * IMG_W + 16 * cb]) = vb;
     } else if (walker) {
         const int x = tx0 - 4 + 4 * g;
         for (int r = r0; r < IMG_H; r += 14) {
