@@ -10,14 +10,15 @@
 // So one pass per level serves both thresholds: every strict per-cell local maximum with
 // A > min(iniThFAST, minThFAST) is appended to the level's candidate list, and a per-cell counter records how many
 // of them exceed iniThFAST.  The consumer keeps a candidate iff A > iniThFAST, or its cell has no
-// such candidate (the fallback of :874-878).  Candidates are appended in arbitrary order; each
+// such candidate (the fallback of :874-878).  Candidates are appended to the level's arrays in arbitrary
+// order (a workgroup reserves the slots of its tile with one atomic on the level's counter); each
 // carries an order key (cell-major, then row-major inside the cell), the order in which the
 // reference appends them.
 //
 // Work per 64x64 tile:  stage the image tile (+4 px) in LDS; test every pixel of the tile (+1 px
 // ring) against the four compass points, two pixels per packed 16-bit operation (a 9-arc contains at
 // least one pixel of each antipodal pair); queue the few that pass; compute A only for those, both
-// polarities at once with packed 16-bit min/max; suppress non-maxima; append.
+// polarities at once with packed 16-bit min/max; suppress non-maxima; append to the level's candidate arrays.
 #include "orbx_internal.h"
 
 #ifndef FAST_CUT
@@ -143,9 +144,11 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-__global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, int *__restrict__ tile_cnt,
-                                              uint2 *__restrict__ tile_list, uint8_t *__restrict__ cell_flag,
-                                              const uint32_t *__restrict__ ftile_tab, FastArgs a)
+__global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, int *__restrict__ ncand,
+                                              uint32_t *__restrict__ cand_xy, uint8_t *__restrict__ cand_resp,
+                                              uint32_t *__restrict__ cand_key, uint8_t *__restrict__ cell_flag,
+                                              int *__restrict__ status, const uint32_t *__restrict__ ftile_tab,
+                                              FastArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t img[IMG_H * IMG_W];  // staged pixels
     __shared__ __attribute__((aligned(16))) uint8_t sc[SC_H * SC_P];     // A where it exceeds t_low, else 0
@@ -169,12 +172,8 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     const int wc = a.wcell[lvl], hc = a.hcell[lvl];
     const int x_lo = ORBX_CELL_ORG, x_hi = w - ORBX_CELL_ORG, y_lo = ORBX_CELL_ORG, y_hi = h - ORBX_CELL_ORG;
     // tiles that hold no detectable pixel, and levels without a cell grid, produce nothing
-    int *my_cnt = tile_cnt + (size_t)f * a.tiles_per_frame + unit;
-    if (wc == 0 || tx0 + ORBX_FAST_W <= x_lo || tx0 >= x_hi || ty0 + ORBX_FAST_H <= y_lo || ty0 >= y_hi) {
-        if (threadIdx.x == 0)
-            *my_cnt = 0;
+    if (wc == 0 || tx0 + ORBX_FAST_W <= x_lo || tx0 >= x_hi || ty0 + ORBX_FAST_H <= y_lo || ty0 >= y_hi)
         return;
-    }
     FAST_CUT(0);
     const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
     const int lane = threadIdx.x & 63;
@@ -308,11 +307,14 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     FAST_CUT(3);
 
     // ---- non-maximum suppression inside the pixel's cell, on the tile proper ----
-    // Survivors go to the tile's own list (no global atomics); a later pass concatenates the lists.
-    uint2 *my_list = tile_list + ((size_t)f * a.tiles_per_frame + unit) * ORBX_TILE_CAP;
-    uint8_t *flags = cell_flag + (size_t)f * a.cells_per_frame + a.cell_base[lvl];
+    // Survivors are listed at the bottom of the queue array (its entries are spent; the corner list sits at the
+    // top, and survivors + corners stay below the array's size because survivors <= corners <= half of it).
+    // Then the workgroup reserves its share of the level's candidate arrays with ONE atomic on the level's
+    // counter (an atomic per wave and trip made the kernel 2.5 times slower: a level's counter took a thousand of
+    // them per launch) and writes the records.  The arrays are filled in no particular order; every candidate
+    // carries its order key, which is all the quadtree needs.
     const uint32_t wc_magic = a.wc_magic[lvl], hc_magic = a.hc_magic[lvl];
-    auto suppress = [&](int e) {
+    auto is_maximum = [&](int e) -> bool {
         const int r = e >> 7, c = e & 127;
         const uint8_t *p = &sc[SC_AT(r, c)];
         const int A = p[0];
@@ -328,83 +330,71 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         const int dl = l ? p[SC_P - 1] : 0, dc = p[SC_P], dr = rr ? p[SC_P + 1] : 0;
         const int mu = u ? max(max(ul, uc), ur) : 0, md = dn ? max(max(dl, dc), dr) : 0;
         const int m = max(max(nl, nr), max(mu, md));
-        if (A > m) {
-            const int cell = ci * a.ncols[lvl] + cj;
-            const int k = atomicAdd(&sn, 1);  // LDS; at most ORBX_TILE_CAP strict per-cell maxima fit a tile
-            // x | y<<12 relative to (16,16) | cornerScore<<24 ; order key of the reference's candidate list
-            my_list[k] = make_uint2((uint32_t)(x - ORBX_BORDER) | ((uint32_t)(y - ORBX_BORDER) << 12) |
-                                        ((uint32_t)(A - 1) << 24),
-                                    ((uint32_t)cell << 12) | ((uint32_t)(y - cy0) << 6) | (uint32_t)(x - cx0));
-            if (A > a.t_ini)
-                flags[cell] = 1;  // the cell has a corner above iniThFAST
-        }
+        return A > m;
+    };
+    auto list_survivors = [&](bool have, int e) {
+        const bool keep = have && is_maximum(e);
+        const unsigned long long bal = __ballot(keep);
+        if (bal == 0ull)
+            return;
+        int base = 0;
+        if (lane == 0)
+            base = atomicAdd(&sn, __popcll(bal));  // LDS
+        const int slot = __builtin_amdgcn_readfirstlane(base) + lanes_below(bal);  // (lane 0's value: all lanes active here)
+        if (keep)
+            queue[slot] = (uint16_t)e;
     };
     const int nc = cn;
     if (nc <= QUEUE_CAP - nq) {
-        for (int i = threadIdx.x; i < nc; i += 256)
-            suppress(queue[QUEUE_CAP - 1 - i]);
+        for (int i0 = 0; i0 < nc; i0 += 256) {
+            const int i = i0 + threadIdx.x;
+            list_survivors(i < nc, i < nc ? queue[QUEUE_CAP - 1 - i] : 0);
+        }
     } else {
-        // the corner list ran into the queue: visit every pixel of the tile
+        // the corner list ran into the queue: visit every pixel of the tile (at most a quarter of them can be
+        // strict maxima, so the list below stays inside the array)
         for (int i = threadIdx.x; i < ORBX_FAST_W * ORBX_FAST_H; i += 256) {
             const int r = 4 + i / ORBX_FAST_W, c = IMG_X0 + i % ORBX_FAST_W;
-            if (sc[SC_AT(r, c)])
-                suppress((r << 7) | c);
+            list_survivors(sc[SC_AT(r, c)] != 0, (r << 7) | c);
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0)
-        *my_cnt = sn;
-}
-
-// Concatenates the tile lists of every (frame, level) into the level's candidate arrays.
-// One workgroup per tile: its offset is the sum of the counts of the level's earlier tiles.
-__global__ __launch_bounds__(64) void k_gather(const int *__restrict__ tile_cnt, const uint2 *__restrict__ tile_list,
-                                               int *__restrict__ ncand, uint32_t *__restrict__ cand_xy,
-                                               uint8_t *__restrict__ cand_resp, uint32_t *__restrict__ cand_key,
-                                               int *__restrict__ status, const uint32_t *__restrict__ ftile_tab,
-                                               FastArgs a)
-{
-    const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
-    if (f >= a.batch)
+    // the first wave alone writes the records (a tile keeps about 45 candidates): no second barrier, and the
+    // other waves retire
+    const int ns = sn;
+    if (ns == 0 || threadIdx.x >= 64)
         return;
-    const int lvl = ftile_tab[unit] >> 24;
-    const int first = a.tile_base[lvl], ntiles = a.tile_base[lvl + 1] - first;
-    const int me = unit - first;
-    const int *cnt = tile_cnt + (size_t)f * a.tiles_per_frame + first;
-    const int lane = threadIdx.x;
-    // candidates of the level's earlier tiles (every wave), and of all its tiles (the first tile's wave only):
-    // sums over the lanes on the data-parallel-primitive path, not through LDS permutes
-    int before = 0;
-    for (int i = lane; i < me; i += 64)
-        before += cnt[i];
-    before = __builtin_amdgcn_readlane(orbx_wave_scan_add_i32(before), 63);
-    const int cap = a.cand_cap[lvl];
-    if (me == 0) {
-        int all = 0;
-        for (int i = lane; i < ntiles; i += 64)
-            all += cnt[i];
-        all = __builtin_amdgcn_readlane(orbx_wave_scan_add_i32(all), 63);
-        if (lane == 0) {
-            ncand[f * a.nlevels + lvl] = all;
-            if (all > cap)
-                atomicMax(&status[ORBX_ST_CAND_OVERFLOW], all);
-        }
-    }
-    const int mine = cnt[me];
-    const uint2 *src = tile_list + ((size_t)f * a.tiles_per_frame + unit) * ORBX_TILE_CAP;
+    int first = 0;
+    if (lane == 0)
+        first = atomicAdd(ncand + f * a.nlevels + lvl, ns);  // the slot of the tile's first record
+    first = __builtin_amdgcn_readfirstlane(first);
+    uint8_t *flags = cell_flag + (size_t)f * a.cells_per_frame + a.cell_base[lvl];
     const size_t cb = (size_t)f * a.cand_per_frame + a.cand_base[lvl];
-    for (int j = lane; j < mine; j += 64) {
-        const int k = before + j;
+    const int cap = a.cand_cap[lvl];
+    if (first + ns > cap && lane == 0)
+        atomicMax(&status[ORBX_ST_CAND_OVERFLOW], first + ns);
+    for (int i = lane; i < ns; i += 64) {
+        const int e = queue[i];
+        const int r = e >> 7, c = e & 127;
+        const int A = sc[SC_AT(r, c)];
+        const int y = ty0 - 4 + r, x = tx0 - IMG_X0 + c;
+        const int cj = (int)(((uint32_t)(x - ORBX_CELL_ORG) * wc_magic) >> 20);
+        const int ci = (int)(((uint32_t)(y - ORBX_CELL_ORG) * hc_magic) >> 20);
+        const int cell = ci * a.ncols[lvl] + cj;
+        const int k = first + i;
         if (k < cap) {
-            const uint2 v = src[j];
-            cand_xy[cb + k] = (v.x & 0xfffu) | (((v.x >> 12) & 0xfffu) << 16);
-            cand_resp[cb + k] = (uint8_t)(v.x >> 24);
-            cand_key[cb + k] = v.y;
+            // x | y<<16 relative to (16,16), cornerScore, order key of the reference's candidate list
+            cand_xy[cb + k] = (uint32_t)(x - ORBX_BORDER) | ((uint32_t)(y - ORBX_BORDER) << 16);
+            cand_resp[cb + k] = (uint8_t)(A - 1);
+            cand_key[cb + k] = ((uint32_t)cell << 12) | ((uint32_t)(y - (ORBX_CELL_ORG + ci * hc)) << 6) |
+                               (uint32_t)(x - (ORBX_CELL_ORG + cj * wc));
         }
+        if (A > a.t_ini)
+            flags[cell] = 1;  // the cell has a corner above iniThFAST
     }
 }
 
-// part 0: clear the per-cell flags, 1: detection, 2: compaction of the tile lists
+// part 0: clear the per-cell flags and the candidate counts, 1: detection
 hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s, int part)
 {
     FastArgs a;
@@ -429,15 +419,13 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
         a.hc_magic[l] = L.hcell > 0 ? ((1u << 20) + L.hcell - 1) / L.hcell : 0u;
     }
     a.tile_base[g.nlevels] = g.ftiles_per_frame;
-    if (part == 0)
-        return g.cells_per_frame > 0 ? hipMemsetAsync(b.cell_flag, 0, (size_t)g.batch * g.cells_per_frame, s)
-                                     : hipSuccess;
-    const dim3 grid = orbx_frame_grid(g.ftiles_per_frame, g.batch);
-    if (part == 1) {
-        k_fast<<<grid, 256, 0, s>>>(b.pyr, b.tile_cnt, b.tile_list, b.cell_flag, b.tile_tab + g.tiles_per_frame, a);
-        return hipGetLastError();
+    if (part == 0) {
+        // the flags lie behind the counts in one allocation: one fill
+        const uint8_t *lo = reinterpret_cast<const uint8_t *>(b.ncand);
+        return hipMemsetAsync(b.ncand, 0, (size_t)(b.cell_flag - lo) + (size_t)g.batch * g.cells_per_frame, s);
     }
-    k_gather<<<grid, 64, 0, s>>>(b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.status,
-                                 b.tile_tab + g.tiles_per_frame, a);
+    const dim3 grid = orbx_frame_grid(g.ftiles_per_frame, g.batch);
+    k_fast<<<grid, 256, 0, s>>>(b.pyr, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.status,
+                                b.tile_tab + g.tiles_per_frame, a);
     return hipGetLastError();
 }

@@ -319,7 +319,7 @@ template <typename T> static hipError_t dmalloc(T **p, size_t n)
 static void free_buffers(orbx_extractor *ex)
 {
     OrbxBuffers &b = ex->buf;
-    void *ptrs[] = {b.pyr,       b.blur,    b.cell_flag, b.tile_cnt, b.tile_list, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
+    void *ptrs[] = {b.pyr,       b.blur,    b.ncand /* and cell_flag */, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
                     b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n,   ex->d_ptab, ex->d_xtab,
                     ex->d_ytab,  ex->d_tiletab, ex->d_blur_bands};
     for (void *p : ptrs)
@@ -418,10 +418,13 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     // 256 bytes of slack: window copies read whole words that may run past the last row
     if (e == hipSuccess) e = dmalloc(&b.pyr, B * g.slab + 256);
     if (e == hipSuccess) e = dmalloc(&b.blur, B * g.bslab + 256);
-    if (e == hipSuccess) e = dmalloc(&b.cell_flag, B * g.cells_per_frame);
-    if (e == hipSuccess) e = dmalloc(&b.tile_cnt, B * g.ftiles_per_frame);
-    if (e == hipSuccess) e = dmalloc(&b.tile_list, B * g.ftiles_per_frame * ORBX_TILE_CAP);
-    if (e == hipSuccess) e = dmalloc(&b.ncand, B * g.nlevels);
+    // candidate counts and per-cell flags in one allocation (counts first): one fill clears both before detection
+    if (e == hipSuccess) {
+        uint8_t *both = nullptr;
+        e = dmalloc(&both, B * g.nlevels * sizeof(int) + B * g.cells_per_frame);
+        b.ncand = reinterpret_cast<int *>(both);
+        b.cell_flag = both ? both + B * g.nlevels * sizeof(int) : nullptr;
+    }
     if (e == hipSuccess) e = dmalloc(&b.cand_xy, B * g.cand_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.cand_resp, B * g.cand_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.cand_key, B * g.cand_per_frame);
@@ -640,7 +643,6 @@ static int run_pipeline(orbx_extractor *ex)
     HIP_TRY(orbx_launch_fast(g, b, s, 1));
     HIP_TRY(prof_mark(ex, 2, 1, s));
     HIP_TRY(prof_mark(ex, 3, 0, s));
-    HIP_TRY(orbx_launch_fast(g, b, s, 2));
     HIP_TRY(orbx_launch_octree(g, b, s));
     HIP_TRY(prof_mark(ex, 3, 1, s));
     if (overlap)

@@ -27,9 +27,6 @@
 #define ORBX_FAST_Y0 ORBX_CELL_ORG
 #define ORBX_FAST_TILES_X(w) ((w) - ORBX_CELL_ORG - ORBX_FAST_X0 > 0 ? ((w) - ORBX_CELL_ORG - ORBX_FAST_X0 + ORBX_FAST_W - 1) / ORBX_FAST_W : 1)
 #define ORBX_FAST_TILES_Y(h) ((h) - ORBX_CELL_ORG - ORBX_FAST_Y0 > 0 ? ((h) - ORBX_CELL_ORG - ORBX_FAST_Y0 + ORBX_FAST_H - 1) / ORBX_FAST_H : 1)
-// A FAST tile holds at most 34 x 34 strict per-cell local maxima (one per 2x2 pixels of a cell,
-// cells at least 30 px wide): capacity of a tile's candidate list
-#define ORBX_TILE_CAP 1160
 
 // Blurred levels are stored as tiles of 16 x 8 pixels = one 128-byte cache line, tile rows of pitch / 16 tiles
 // (pitch * 8 bytes), h / 8 + 2 tile rows per level.  Inside a tile: two halves of 4 rows (64 bytes), each made of
@@ -102,9 +99,8 @@ struct OrbxBuffers {
     uint8_t *pyr;     // [batch][slab] pyramid levels (level 0 only when the frames had to be copied)
     uint8_t *blur;    // [batch][bslab] blurred levels in 16 x 8-pixel tiles of one 128-byte line (ORBX_BLUR_ADDR)
     uint8_t *cell_flag;  // [batch][cells_per_frame] 1: the cell has a candidate whose score exceeds iniThFAST
-    int *tile_cnt;       // [batch][ftiles_per_frame] candidates found in each FAST tile
-    uint2 *tile_list;    // [batch][ftiles_per_frame][ORBX_TILE_CAP] x | y<<12 | score<<24 , order key
-    int *ncand;       // [batch][nlevels] candidates appended (before the per-cell threshold decision)
+    int *ncand;       // [batch][nlevels] candidates appended (before the per-cell threshold decision); cell_flag
+                      // lies behind it in the same allocation
     uint32_t *cand_xy;   // [batch][cand_per_frame] x | y<<16, relative to (16,16); arbitrary order
     uint8_t *cand_resp;  // [batch][cand_per_frame] cornerScore = A-1
     uint32_t *cand_key;  // [batch][cand_per_frame] cell<<12 | row-in-cell<<6 | col-in-cell: the reference's order
@@ -182,6 +178,7 @@ hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, c
 hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 // levels `level` and `level + 1` from level `level - 1` in one launch
 hipError_t orbx_launch_resize_pair(int level, const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
+// part 0: clears the candidate counts and per-cell flags; part 1: detection, which appends to the candidate arrays
 hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s, int part);
 hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);
 hipError_t orbx_launch_blur(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s);

@@ -1,6 +1,6 @@
 // Where the time of the detection kernel goes: runs k_fast (the kernel body of the library, included as
 // source) on the pyramids of a batch of benchmark frames, whole and cut short after each of its phases
-// (staging, compass test + queue, arc score, non-maximum suppression + lists).  The pyramids come from
+// (staging, compass test + queue, arc score, non-maximum suppression + candidate records).  The pyramids come from
 // the library itself (liborbx.so: extraction of synthetic KITTI-shape frames, levels read back).
 // usage: bin/exp_fast [frames] [reps]
 #include <hip/hip_runtime.h>
@@ -11,15 +11,11 @@
 #include <vector>
 
 __device__ int g_fast_cut;
-#define FAST_CUT(n)                  \
-    if (g_fast_cut == (n)) {         \
-        if (threadIdx.x == 0)        \
-            *my_cnt = 0;             \
-        return;                      \
-    }
+#define FAST_CUT(n)          \
+    if (g_fast_cut == (n))   \
+        return;
 // the library this program links for its pyramids exports kernels of the same names
 #define k_fast k_fast_exp
-#define k_gather k_gather_exp
 #define orbx_launch_fast orbx_launch_fast_exp
 #include "fast.hip"
 
@@ -84,13 +80,16 @@ int main(int argc, char **argv)
     a.tile_base[NL] = tiles;
     a.slab = (int)off, a.cells_per_frame = cells, a.tiles_per_frame = tiles, a.cand_per_frame = cand;
     // B frames with their pyramids, eight at a time through the library
-    uint8_t *d_pyr, *d_flag;
-    int *d_cnt;
-    uint2 *d_list;
+    uint8_t *d_pyr, *d_flag, *d_resp;
+    int *d_cnt, *d_status;
+    uint32_t *d_xy, *d_key;
     CK(hipMalloc(&d_pyr, (size_t)B * a.slab + 256));
     CK(hipMalloc(&d_flag, (size_t)B * cells));
-    CK(hipMalloc(&d_cnt, (size_t)B * tiles * 4));
-    CK(hipMalloc(&d_list, (size_t)B * tiles * ORBX_TILE_CAP * 8));
+    CK(hipMalloc(&d_cnt, (size_t)B * NL * 4));
+    CK(hipMalloc(&d_status, 64));
+    CK(hipMalloc(&d_xy, (size_t)B * cand * 4));
+    CK(hipMalloc(&d_key, (size_t)B * cand * 4));
+    CK(hipMalloc(&d_resp, (size_t)B * cand));
     uint32_t *d_tab;
     CK(hipMalloc(&d_tab, tile_tab.size() * 4));
     CK(hipMemcpy(d_tab, tile_tab.data(), tile_tab.size() * 4, hipMemcpyHostToDevice));
@@ -121,15 +120,18 @@ int main(int argc, char **argv)
     for (int cut = 0; cut <= 4; cut++) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_cut), &cut, 4));
         for (int r = 0; r < 3; r++)
-            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_list, d_flag, d_tab, a);
+            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_xy, d_resp, d_key, d_flag, d_status, d_tab, a);
+        CK(hipMemset(d_cnt, 0, (size_t)B * NL * 4));
         CK(hipEventRecord(e0, 0));
-        for (int r = 0; r < reps; r++)
-            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_list, d_flag, d_tab, a);
+        for (int r = 0; r < reps; r++) {
+            CK(hipMemsetAsync(d_cnt, 0, (size_t)B * NL * 4, 0));  // as the library does before every detection
+            k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_xy, d_resp, d_key, d_flag, d_status, d_tab, a);
+        }
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(&t[cut], e0, e1));
         t[cut] /= reps;
-        std::vector<int> cnt((size_t)B * tiles);
+        std::vector<int> cnt((size_t)B * NL);
         CK(hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
         found[cut] = 0;
         for (int c : cnt)
