@@ -10,7 +10,8 @@ mkdir -p "$DST"
 for f in bench_default.json bench_exclusive.json exp_fast.txt exp_octree.txt latency_breakdown.txt pcie_rate.txt \
          pmc_top2.txt probe_mfma_f4.txt top2_harness.txt ubench_mfma_fill.txt ubench_mfma_i8.txt ubench_valu.txt \
          ubench_ta.txt sfi_time.txt bow_rate.json config5_pairs.json distinctive_rate.json projection_rate.json \
-         stereo_rate.json voc_rate.json; do
+         stereo_rate.json voc_rate.json blur_mfma_ab.txt bench_gloo_2ranks_no_launcher.json \
+         bench_nccl_1rank_forced_dist.json test_sharded_rccl.txt probe_mfma_i8_16.txt; do
   [ -f "$SRC/$f" ] && cp "$SRC/$f" "$DST/$f"
 done
 # the newest kernel-trace summary of each command

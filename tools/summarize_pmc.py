@@ -48,7 +48,7 @@ def main():
     lines.append("%-11s %8s %12s %12s %12s %12s %12s %10s" % (
         "kernel", "launches", "FETCH KiB", "WRITE KiB", "HBM MB", "VALU instr", "SALU instr", "LDS instr"))
     kernels = {}
-    for k in ("k_resize", "k_fast", "k_gather", "k_octree", "k_blur", "k_describe"):
+    for k in ("k_resize", "k_fast", "k_octree", "k_blur", "k_describe"):
         per_batch = 7 if k == "k_resize" else 1  # launches per batch (one resize per level above 0)
         f = mean(fetch[k]["FETCH_SIZE"]) * per_batch
         w = mean(write[k]["WRITE_SIZE"]) * per_batch
@@ -68,7 +68,7 @@ def main():
         lines.append("vector memory path per launch (TA_TA_BUSY summed over the 256 compute units, GRBM_GUI_ACTIVE over the 8 XCDs):")
         lines.append("%-11s %14s %16s %16s %16s %10s" % (
             "kernel", "TA busy cyc", "L1 accesses", "L1->L2 reads", "pending stall", "TA busy"))
-        for k in ("k_resize", "k_fast", "k_gather", "k_octree", "k_blur", "k_describe"):
+        for k in ("k_resize", "k_fast", "k_octree", "k_blur", "k_describe"):
             c = {n: mean(v) for n, v in l1[k].items()}
             active = c["GRBM_GUI_ACTIVE"] / 8.0
             lines.append("%-11s %14.0f %16.0f %16.0f %16.0f %9.0f%%" % (
@@ -76,6 +76,22 @@ def main():
                 c["TCP_PENDING_STALL_CYCLES_sum"], 100.0 * c["TA_TA_BUSY_sum"] / 256.0 / active))
             kernels[k]["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / 256.0 / active
             kernels[k]["l1_to_l2_read_requests_per_frame"] = c["TCP_TCC_READ_REQ_sum"] / frames
+    ldsdir = os.path.join(src, "pmc_lds")
+    if os.path.isdir(ldsdir):
+        ld = load(ldsdir)
+        lines.append("")
+        lines.append("LDS per launch (SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT: cycles summed over the 256 compute units; "
+                     "SQ_BUSY_CYCLES over the 32 shader engines):")
+        lines.append("%-11s %14s %16s %12s %18s" % ("kernel", "LDS instr", "LDS active cyc", "conflict", "LDS busy of time"))
+        for k in ("k_fast", "k_octree", "k_blur", "k_describe"):
+            c = {n: mean(v) for n, v in ld[k].items()}
+            busy = c["SQ_BUSY_CYCLES"] / 32.0
+            lines.append("%-11s %14.0f %16.0f %11.0f%% %17.0f%%" % (
+                k, c["SQ_INSTS_LDS"], c["SQ_LDS_IDX_ACTIVE"],
+                100.0 * c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0),
+                100.0 * c["SQ_LDS_IDX_ACTIVE"] / 256.0 / busy))
+            kernels[k]["lds_bank_conflict_frac"] = c["SQ_LDS_BANK_CONFLICT"] / max(c["SQ_LDS_IDX_ACTIVE"], 1.0)
+            kernels[k]["lds_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / 256.0 / busy
     out = {"workload": bench["config"]["workload"], "frames_per_launch_measured": frames,
            "source": "%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_* passes of "
                      "'bench.py --exclusive', HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB" % dst,
