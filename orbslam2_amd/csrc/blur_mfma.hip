@@ -81,25 +81,20 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const uint8_t *__restrict__ p
         const int tx0 = cur.tx0, ty0 = cur.ty0, h = cur.h, pitch = a.pitch[lvl];
         uint8_t *dst = dst_frame + a.boff[lvl];
         uint32_t *stage = img[k & 1];
-        blur_stage_commit(stage, cur, fx);
+        blur_stage_commit<true>(stage, cur, fx);  // staged as pixel - 128
         __syncthreads();
         if (k + 1 < nunits) {
             next = tile_of(unit0 + k + 1, lvl_next);
             blur_stage_fetch(next, fx);
         }
         const uint8_t *sb = reinterpret_cast<const uint8_t *>(stage);
-        auto piece = [&](int o) -> bm_v4i {
-            bm_v4i v = *reinterpret_cast<const bm_v4i *>(sb + o);
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                v[i] ^= (int)0x80808080u;
-            return v;
-        };
+        auto piece = [&](int o) -> bm_v4i { return *reinterpret_cast<const bm_v4i *>(sb + o); };
         // lane = output row (n of 16) and 4-pixel group (q of 4): first byte of its quad in column block 0, row block 0
         const int y = ty0 + n, x = tx0 + 32 * wv + 4 * q;
         uint8_t *d0 = dst + (uint32_t)ORBX_BLUR_ADDR(x, y, pitch);
         const int h8 = (h + 7) & ~7;  // rows of the level's last tile row are written: zeros below the level
         const bool cols_ok = x < pitch;
+        const bool full = ty0 + BL_H <= h;  // every row of the tile exists (all tiles but a level's last row of them)
 #pragma unroll
         for (int cb = 0; cb < 2; cb++) {
             // horizontal pass of 16 columns: staged rows 0..15, 16..31, 32..37
@@ -128,8 +123,13 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const uint8_t *__restrict__ p
                                    __builtin_amdgcn_perm(s[3], s[2], 0x06020c0cu);
                 const int yy = y + 16 * ob;
                 // 16 columns on: the next tile of the blurred level; 16 rows on: two tile rows down
-                if (cols_ok && yy < h8)
-                    *reinterpret_cast<uint32_t *>(d0 + cb * 128 + ob * (16 * pitch)) = yy < h ? o : 0u;
+                uint32_t *dq = reinterpret_cast<uint32_t *>(d0 + cb * 128 + ob * (16 * pitch));
+                if (full) {
+                    if (cols_ok)
+                        *dq = o;
+                } else if (cols_ok && yy < h8) {
+                    *dq = yy < h ? o : 0u;
+                }
             }
         }
     }

@@ -37,10 +37,13 @@ struct BlurTile {
                ty0 + BL_H + 3 <= h;
     }
 };
-// What a thread has fetched of a tile and not yet written to LDS: up to two 16-byte pieces and one border byte.
+// What a thread has fetched of a tile and not yet written to LDS: up to two 16-byte pieces and one border byte,
+// each with its place in the staged tile (negative: nothing to store).
 struct BlurFetch {
     uint4 v[2];
+    int dst[2];  // word index of the piece in the staged tile
     uint32_t patch;
+    int pdst;    // byte index of the border byte
 };
 
 // Staging in two steps, so that a kernel that loops over tiles can have the next tile's loads in flight while it
@@ -59,70 +62,65 @@ __device__ __forceinline__ void blur_stage_fetch(const BlurTile &t, BlurFetch &f
     if (!t.aligned())
         return;
     const bool interior = t.interior();
-    const int npairs = t.npairs();
+    const int nitems = 2 * t.npairs() * (BL_SWORDS / 4);  // 38 rows x 10 pieces = 380 items at most
     // readable bytes of the level
     const uint32_t src_bytes = (uint32_t)t.spitch * (uint32_t)(t.h - 1) + (uint32_t)(t.level0 ? t.w : t.spitch);
+    // the thread's items i = threadIdx.x and i + 256: row i / 10, piece i % 10; 256 = 25 * 10 + 6
+    const int r0 = (int)(__umul24(threadIdx.x, 6554u) >> 16), c0 = (int)threadIdx.x - 10 * r0;
+    const bool wrap = c0 >= 4;
+    const int rr[2] = {r0, r0 + (wrap ? 26 : 25)}, cc[2] = {c0, wrap ? c0 - 4 : c0 + 6};
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const int i = threadIdx.x + 256 * k;  // 38 rows x 10 pieces = 380 items
-        fx.v[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (i < 2 * npairs * (BL_SWORDS / 4)) {
-            const int r = i / (BL_SWORDS / 4), c = i % (BL_SWORDS / 4);
-            const int x0 = t.tx0 - BL_LEFT + 16 * c;
+        const int r = rr[k], c = cc[k];
+        const int x0 = t.tx0 - BL_LEFT + 16 * c;
+        fx.dst[k] = -1;
+        if ((int)threadIdx.x + 256 * k < nitems && (interior || (x0 >= 0 && x0 + 16 <= t.spitch))) {
+            fx.dst[k] = r * BL_SWORDS + 4 * c;
             const int sy = interior ? t.ty0 - 3 + r : reflect101(t.ty0 - 3 + r, t.h);
-            if (interior || (x0 >= 0 && x0 + 16 <= t.spitch)) {
-                const uint32_t o = (uint32_t)(__umul24(sy, t.spitch) + x0);
-                if (interior || o + 16u <= src_bytes) {
-                    fx.v[k] = *reinterpret_cast<const uint4 *>(t.src + o);
-                } else {
-                    // the last pieces of the last row: pixels only
-                    uint32_t q[4] = {0, 0, 0, 0};
-                    for (int b = 0; b < 16; b++)
-                        if (x0 + b < t.w)
-                            q[b >> 2] |= (uint32_t)t.src[o + b] << (8 * (b & 3));
-                    fx.v[k] = make_uint4(q[0], q[1], q[2], q[3]);
-                }
+            const uint32_t o = (uint32_t)(__umul24(sy, t.spitch) + x0);
+            if (interior || o + 16u <= src_bytes) {
+                fx.v[k] = *reinterpret_cast<const uint4 *>(t.src + o);
+            } else {
+                // the last pieces of the last row: pixels only
+                uint32_t q[4] = {0, 0, 0, 0};
+                for (int b = 0; b < 16; b++)
+                    if (x0 + b < t.w)
+                        q[b >> 2] |= (uint32_t)t.src[o + b] << (8 * (b & 3));
+                fx.v[k] = make_uint4(q[0], q[1], q[2], q[3]);
             }
         }
     }
-    fx.patch = 0;
+    fx.pdst = -1;
     if (!interior && threadIdx.x < BL_SH * 6) {
-        const int r = threadIdx.x / 6, k = threadIdx.x % 6;
+        const int r = (int)(__umul24(threadIdx.x, 10923u) >> 16), k = (int)threadIdx.x - 6 * r;
         const int x = k < 3 ? -1 - k : t.w + k - 3;
         const int col = x - (t.tx0 - BL_LEFT);  // staged byte column
-        if (col >= 0 && col < 4 * BL_SWORDS)
+        if (col >= 0 && col < 4 * BL_SWORDS) {
+            fx.pdst = r * (4 * BL_SWORDS) + col;
             fx.patch = t.src[(uint32_t)__umul24(reflect101(t.ty0 - 3 + r, t.h), t.spitch) + reflect101(x, t.w)];
+        }
     }
 }
 
 // Writes the fetched pieces to LDS (with a barrier of its own before the border bytes of a tile that is not
-// interior); the caller synchronises the workgroup afterwards.
+// interior); the caller synchronises the workgroup afterwards.  Flip: every staged byte is stored as
+// pixel ^ 0x80, i.e. pixel - 128 as a signed byte (the matrix-core kernel's operand form).
+template <bool Flip = false>
 __device__ __forceinline__ void blur_stage_commit(uint32_t *img, const BlurTile &t, const BlurFetch &fx)
 {
+    const uint32_t flip = Flip ? 0x80808080u : 0u;
     const int tx0 = t.tx0, ty0 = t.ty0, w = t.w, h = t.h, spitch = t.spitch;
     const uint8_t *src = t.src;
     if (t.aligned()) {
-        const bool interior = t.interior();
-        const int npairs = t.npairs();
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = threadIdx.x + 256 * k;
-            if (i < 2 * npairs * (BL_SWORDS / 4)) {
-                const int r = i / (BL_SWORDS / 4), c = i % (BL_SWORDS / 4);
-                const int x0 = tx0 - BL_LEFT + 16 * c;
-                if (interior || (x0 >= 0 && x0 + 16 <= spitch))
-                    *reinterpret_cast<uint4 *>(&img[r * BL_SWORDS + 4 * c]) = fx.v[k];
-            }
-        }
-        if (!interior) {
+        for (int k = 0; k < 2; k++)
+            if (fx.dst[k] >= 0)
+                *reinterpret_cast<uint4 *>(&img[fx.dst[k]]) =
+                    make_uint4(fx.v[k].x ^ flip, fx.v[k].y ^ flip, fx.v[k].z ^ flip, fx.v[k].w ^ flip);
+        if (!t.interior()) {
             __syncthreads();
-            if (threadIdx.x < BL_SH * 6) {
-                const int r = threadIdx.x / 6, k = threadIdx.x % 6;
-                const int x = k < 3 ? -1 - k : w + k - 3;
-                const int col = x - (tx0 - BL_LEFT);  // staged byte column
-                if (col >= 0 && col < 4 * BL_SWORDS)
-                    reinterpret_cast<uint8_t *>(img)[r * (4 * BL_SWORDS) + col] = (uint8_t)fx.patch;
-            }
+            if (fx.pdst >= 0)
+                reinterpret_cast<uint8_t *>(img)[fx.pdst] = (uint8_t)(fx.patch ^ (flip & 0x80u));
         }
     } else {
         // unaligned level (a caller's level 0 at an odd address or pitch): rows and columns outside the image
@@ -155,7 +153,7 @@ __device__ __forceinline__ void blur_stage_commit(uint32_t *img, const BlurTile 
             for (int k = 0; k < (BL_SH + 3) / 4; k++) {
                 const int r = (threadIdx.x >> 6) + 4 * k;
                 if (r < BL_SH)
-                    img[r * BL_SWORDS + 3 + c4] = v[k];
+                    img[r * BL_SWORDS + 3 + c4] = v[k] ^ flip;
             }
         }
     }
