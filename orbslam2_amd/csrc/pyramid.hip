@@ -115,52 +115,65 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
 #pragma unroll
     for (int d = 0; d < RS_ROWS; d++)
         C[d] = yt[__builtin_amdgcn_readfirstlane(min(dy0 + d, dy1 - 1))];
-    // Destination rows in turn; `cur` holds the horizontal pass of source row j, `prev` that of row j - 1, and the
-    // row after j is loading.  A destination row reads source rows (sy1 - 1, sy1), or (sy1, sy1) where the table
-    // clamps at the border; j advances to sy1 by one step mostly, by two where the ratio skips a source row.
-    int j = C[0].sy0;
-    uint32_t ahead[3] = {0, 0, 0}, raw[3], prev[4], cur[4];
-    load_row(j, raw);
-    if (j < (int)last_row)
-        load_row(j + 1, ahead);
-    hpass(j, raw, cur);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-        prev[i] = cur[i];
+    // Destination rows in turn.  A row reads source rows (sy0, sy1) = (sy1 - 1, sy1), or (sy1, sy1) where the table
+    // clamps at the border, and sy1 grows by one from row to row mostly, by two or more where the ratio skips source
+    // rows.  The horizontal passes of the two rows sit in H[0] and H[1]; before destination row d the newest one
+    // (source row j) is in H[d & 1].  One step: the row keeps it as its upper row and filters sy1 into the other
+    // array; more: it filters both its rows anew; none (clamped rows at the bottom): the arrays change places.  So
+    // no register is copied on the common paths.  The raw words of a row's source rows are loaded while the row
+    // before is computed (R[d & 1]: [0] for sy0, [1] for sy1).
+    uint32_t H[2][4], R[2][2][3];
+    int j = C[0].sy1 - 2;  // row 0 filters both its source rows
+    load_row(C[0].sy0, R[0][0]);
+    load_row(C[0].sy1, R[0][1]);
 #pragma unroll
     for (int d = 0; d < RS_ROWS; d++) {
         if (dy0 + d < dy1) {
             const OrbxYCoef c = C[d];
-            while (j < c.sy1) {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    prev[i] = cur[i];
-                raw[0] = ahead[0], raw[1] = ahead[1], raw[2] = ahead[2];
-                j++;
-                if (j < (int)last_row)
-                    load_row(j + 1, ahead);
-                hpass(j, raw, cur);
+            const int q = d & 1;
+            if (d + 1 < RS_ROWS && dy0 + d + 1 < dy1) {
+                const int step = C[d + 1].sy1 - c.sy1;
+                if (step >= 2)
+                    load_row(C[d + 1].sy0, R[q ^ 1][0]);
+                if (step >= 1)
+                    load_row(C[d + 1].sy1, R[q ^ 1][1]);
             }
+            if (c.sy1 - j >= 2) {
+                hpass(c.sy0, R[q][0], H[q]);
+                hpass(c.sy1, R[q][1], H[q ^ 1]);
+            } else if (c.sy1 - j == 1) {
+                hpass(c.sy1, R[q][1], H[q ^ 1]);
+                if (c.sy0 == c.sy1) {  // clamped: both rows are sy1
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        H[q][i] = H[q ^ 1][i];
+                }
+            } else {
+                // the same lower row as the row before: H[q] holds it, H[q ^ 1] the row above it
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t t = H[q][i];
+                    H[q][i] = c.sy0 == c.sy1 ? t : H[q ^ 1][i];
+                    H[q ^ 1][i] = t;
+                }
+            }
+            j = c.sy1;
+            const uint32_t(&prev)[4] = H[q], (&cur)[4] = H[q ^ 1];
             // (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2 for four pixels: the upper halves
-            // of the eight products are gathered two pixels to a register and added, rounded and shifted as
-            // packed 16-bit values (both products stay below 2^27, so 24-bit multiplies are exact)
-            if (c.sy0 == c.sy1) {  // the wave's rows: a branch, taken at the border only
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    prev[i] = cur[i];
-            }
+            // of the eight products are gathered two pixels to a register and added and shifted as packed 16-bit
+            // values (both products stay below 2^27, so 24-bit multiplies are exact; the rounding 2 enters the
+            // upper half of the first product with the multiplication)
             uint32_t p0[4], p1[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                p0[i] = __umul24((uint32_t)c.b0, prev[i]);
+                p0[i] = __umul24((uint32_t)c.b0, prev[i]) + 0x20000u;
                 p1[i] = __umul24((uint32_t)c.b1, cur[i]);
             }
             typedef unsigned short rs_pk __attribute__((ext_vector_type(2)));
             auto pair = [&](int i) -> uint32_t {
                 const uint32_t t = __builtin_amdgcn_perm(p0[i + 1], p0[i], 0x07060302u);  // hi16(p0[i]) | hi16(p0[i+1]) << 16
                 const uint32_t u = __builtin_amdgcn_perm(p1[i + 1], p1[i], 0x07060302u);
-                const rs_pk sum = __builtin_bit_cast(rs_pk, t) + __builtin_bit_cast(rs_pk, u) + (rs_pk){2, 2};
+                const rs_pk sum = __builtin_bit_cast(rs_pk, t) + __builtin_bit_cast(rs_pk, u);
                 return __builtin_bit_cast(uint32_t, (rs_pk)(sum >> (rs_pk){2, 2}));
             };
             put(dy0 + d, __builtin_amdgcn_perm(pair(2), pair(0), 0x06040200u));  // the four low bytes
