@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     if (aligned) {
         const uint8_t *s0 = src + (size_t)(ty0 - 4) * pitch + (tx0 - IMG_X0);
         // both loads of a thread are in flight before its first LDS store
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;  // 72 rows x 6 pieces = 432 items
-        const int ra = i0 / (IMG_W / 16), ca = i0 % (IMG_W / 16), rb = i1 / (IMG_W / 16), cb = i1 % (IMG_W / 16);
+        // 72 rows x 6 pieces = 432 items; a thread takes items i and i + 256 (256 = 42 * 6 + 4)
+        static_assert(IMG_W / 16 == 6, "the item arithmetic below is for six pieces per row");
+        const int ra = (int)(__umul24(threadIdx.x, 10923u) >> 16), ca = (int)threadIdx.x - 6 * ra;
+        const int rb = ra + (ca >= 2 ? 43 : 42), cb = ca >= 2 ? ca - 2 : ca + 4;
         const bool oka = ra < nrows && ca < npieces, okb = rb < nrows && cb < npieces;
         uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
         if (oka)
