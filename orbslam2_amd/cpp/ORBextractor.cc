@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <cassert>
+#include <climits>
 #include <cstring>
+#include <stdexcept>
 
 #include "orbx.hpp"
 
@@ -88,6 +90,9 @@ bool ORBextractor::MaterializePyramid()
     int64_t total = 0;
     orbx::check(orbx_pyramid_layout(impl_->handle(), EDGE_THRESHOLD, off.data(), w.data(), h.data(), &total),
                 "orbx_pyramid_layout");
+    // a cv::Mat row holds at most INT_MAX columns (a padded pyramid of more than 2 GiB: frames beyond 38000 x 38000)
+    if (total <= 0 || total > (int64_t)INT_MAX)
+        throw std::length_error("ORBextractor: the padded pyramid does not fit one cv::Mat row");
     cv::Mat all(1, (int)total, CV_8UC1);
     orbx::check(orbx_pyramid_download(impl_->handle(), 0, EDGE_THRESHOLD, all.data, total), "orbx_pyramid_download");
     for (int l = 0; l < nlevels; l++) {

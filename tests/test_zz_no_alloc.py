@@ -46,8 +46,13 @@ def _both(m, db, q, idx_base=0):
     return outs
 
 
-def test_noalloc_top2_equals_handle_form_on_consecutive_calls(monkeypatch):
+def test_noalloc_top2_equals_handle_form_on_consecutive_calls(monkeypatch, oracle):
     m = orbx.ORBmatcher(0.75)
+    # once against the oracle itself (the handle form is checked against it elsewhere): index base added by hand
+    db, q = _data(5000, 100, 11)
+    _, (b1, a1, s1) = _both(m, db, q, 40)
+    ob, o1, o2 = oracle.match_top2(q, db)
+    assert np.array_equal(b1, ob + 40) and np.array_equal(a1, o1) and np.array_equal(s1, o2)
     # two calls in a row on the same array, the second smaller; then the vector-ALU kernel (below 32
     # queries), an offset index base, and a larger call again
     for ndb, nq, base, seed in [(200000, 2000, 0, 3), (5000, 100, 0, 4), (3001, 20, 1000, 5), (60000, 999, 7, 6)]:
