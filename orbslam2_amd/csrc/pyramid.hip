@@ -38,12 +38,17 @@ hipError_t orbx_launch_ingest(const uint8_t *src, int stride, int64_t fstride, c
 // ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.  Source positions and coefficients come from
 // tables built on the host for the current image size (they depend on the column or row only).
 #ifndef RS_ROWS
-#define RS_ROWS 8  // destination rows per wave
+// Destination rows per wave of the batch kernel.  With 8 the kernel alone is fastest (0.181 ms per 256 frames against
+// 0.197 with 16: twice the waves), but a wave filters the one or two source rows above its strip again, and in a
+// batch, where the kernels of other instances fill the machine anyway, the work saved counts: 16 gives 1.2 % more
+// frames/s than 8; 12, 20, 24 and 32 give less than 16.
+#define RS_ROWS 16
 #endif
+#define RS2_ROWS 8  // the two-level kernel: four waves compute the 32 rows of a tile of the middle level
 
 typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
 
-// A wave produces RS_ROWS destination rows of 256 pixels, each lane 4 adjacent pixels of every row.  The
+// A wave produces ROWS destination rows of 256 pixels, each lane 4 adjacent pixels of every row.  The
 // rows of a wave are uniform, so the wave walks down the source rows its destination rows read and
 // keeps the horizontal pass of the row before: at a scale factor of 1.2 the upper source row of a
 // destination row is the lower one of the row before in four cases of five, so a source row is read
@@ -58,7 +63,7 @@ typedef unsigned short rs_us2 __attribute__((ext_vector_type(2)));
 // points at source pixel (0, 0) (global memory or LDS); `put(dy, word)` receives the four result bytes of a row.
 // LdsSrc: the source is a staged tile in LDS (every 12-byte read that starts at a lane's own first word stays
 // inside the array by construction of its margins; `src_bytes` is not a limit there).
-template <bool LdsSrc = false, typename Put>
+template <int ROWS, bool LdsSrc = false, typename Put>
 __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, uint32_t src_bytes, int dx0, int dy0,
                                             int dy1, const OrbxXCoef *__restrict__ xt,
                                             const OrbxYCoef *__restrict__ yt, Put put)
@@ -111,9 +116,9 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
 
     // The wave's row coefficients, all at once (its rows are uniform: scalar loads), so that the loop below
     // holds no load of them and no wait.  Entries past dy1 repeat the last row's.
-    OrbxYCoef C[RS_ROWS];
+    OrbxYCoef C[ROWS];
 #pragma unroll
-    for (int d = 0; d < RS_ROWS; d++)
+    for (int d = 0; d < ROWS; d++)
         C[d] = yt[__builtin_amdgcn_readfirstlane(min(dy0 + d, dy1 - 1))];
     // Destination rows in turn.  A row reads source rows (sy0, sy1) = (sy1 - 1, sy1), or (sy1, sy1) where the table
     // clamps at the border, and sy1 grows by one from row to row mostly, by two or more where the ratio skips source
@@ -127,11 +132,11 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
     load_row(C[0].sy0, R[0][0]);
     load_row(C[0].sy1, R[0][1]);
 #pragma unroll
-    for (int d = 0; d < RS_ROWS; d++) {
+    for (int d = 0; d < ROWS; d++) {
         if (dy0 + d < dy1) {
             const OrbxYCoef c = C[d];
             const int q = d & 1;
-            if (d + 1 < RS_ROWS && dy0 + d + 1 < dy1) {
+            if (d + 1 < ROWS && dy0 + d + 1 < dy1) {
                 const int step = C[d + 1].sy1 - c.sy1;
                 if (step >= 2)
                     load_row(C[d + 1].sy0, R[q ^ 1][0]);
@@ -181,21 +186,22 @@ __device__ __forceinline__ void resize_rows(const uint8_t *sbase, int spitch, ui
     }
 }
 
+template <int ROWS>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_lvl, long long src_fstride,
                                                 uint32_t src_bytes, uint8_t *__restrict__ pyr_out, int slab, int spitch,
                                                 int doff, int dpitch, int dw, int dh,
                                                 const OrbxXCoef *__restrict__ xt, const OrbxYCoef *__restrict__ yt)
 {
     const int f = blockIdx.z;
-    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS);
+    const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS);
     const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
     if (dy0 >= dh || dx0 >= dw)
         return;
     uint8_t *dbase = pyr_out + (size_t)f * slab + doff;
-    resize_rows(src_lvl + (size_t)f * src_fstride, spitch, src_bytes, dx0, dy0, min(dy0 + RS_ROWS, dh), xt, yt,
-                [&](int dy, uint32_t out) {
-                    *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy, dpitch) + dx0)) = out;
-                });
+    resize_rows<ROWS>(src_lvl + (size_t)f * src_fstride, spitch, src_bytes, dx0, dy0, min(dy0 + ROWS, dh), xt, yt,
+                         [&](int dy, uint32_t out) {
+                             *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy, dpitch) + dx0)) = out;
+                         });
 }
 
 // ---- two levels in one launch (calls of a few frames, whose time is mostly launches) ----
@@ -223,11 +229,11 @@ __global__ __launch_bounds__(256) void k_resize_pair(const uint8_t *__restrict__
     const int X1 = blockIdx.x * ORBX_RS2_TW, Y1 = blockIdx.y * ORBX_RS2_TH;
     {
         const int dx0 = X1 + 4 * lane;
-        const int dy0 = __builtin_amdgcn_readfirstlane(Y1 + RS_ROWS * wv);
+        const int dy0 = __builtin_amdgcn_readfirstlane(Y1 + RS2_ROWS * wv);
         if (dy0 < mh && dx0 < mw) {
             uint8_t *dbase = pyr_out + (size_t)f * slab + moff;
             uint8_t *lbase = mid + RS2_PAD + 4 * lane;
-            resize_rows(src_lvl + (size_t)f * src_fstride, spitch, src_bytes, dx0, dy0, min(dy0 + RS_ROWS, mh), mxt, myt,
+            resize_rows<RS2_ROWS>(src_lvl + (size_t)f * src_fstride, spitch, src_bytes, dx0, dy0, min(dy0 + RS2_ROWS, mh), mxt, myt,
                         [&](int dy, uint32_t out) {
                             *reinterpret_cast<uint32_t *>(dbase + (uint32_t)(__umul24(dy, mpitch) + dx0)) = out;
                             *reinterpret_cast<uint32_t *>(lbase + __umul24(dy - Y1, RS2_PITCH)) = out;
@@ -238,13 +244,13 @@ __global__ __launch_bounds__(256) void k_resize_pair(const uint8_t *__restrict__
     const int x2a = pcol[blockIdx.x], x2b = pcol[blockIdx.x + 1];
     const int y2a = prow[blockIdx.y], y2b = prow[blockIdx.y + 1];
     const int gx0 = (x2a & ~3) + 4 * lane;
-    const int ry0 = __builtin_amdgcn_readfirstlane(y2a + RS_ROWS * wv);
+    const int ry0 = __builtin_amdgcn_readfirstlane(y2a + RS2_ROWS * wv);
     if (ry0 < y2b && gx0 < x2b) {
         uint8_t *tbase = pyr_out + (size_t)f * slab + toff;
         const bool whole = gx0 >= x2a && gx0 + 4 <= x2b;
         // LDS address of middle-level pixel (0, 0): pixel (X, Y) lies at mid[(Y - Y1) * RS2_PITCH + RS2_PAD + X - X1]
         const uint8_t *origin = mid + RS2_PAD - X1 - Y1 * RS2_PITCH;
-        resize_rows<true>(origin, RS2_PITCH, 0xffffffffu, gx0, ry0, min(ry0 + RS_ROWS, y2b), txt, tyt, [&](int dy, uint32_t out) {
+        resize_rows<RS2_ROWS, true>(origin, RS2_PITCH, 0xffffffffu, gx0, ry0, min(ry0 + RS2_ROWS, y2b), txt, tyt, [&](int dy, uint32_t out) {
             uint8_t *d = tbase + (uint32_t)(__umul24(dy, tpitch) + gx0);
             if (whole) {
                 *reinterpret_cast<uint32_t *>(d) = out;
@@ -278,14 +284,20 @@ hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b
 {
     const OrbxLevel &S = g.lv[level - 1];
     const OrbxLevel &D = g.lv[level];
-    dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), g.batch);
+    // a few frames do not fill the machine: the shorter strips give twice the waves
+    const int rows = g.batch >= 32 ? RS_ROWS : RS2_ROWS;
+    dim3 grid((D.w + 255) / 256, (D.h + 4 * rows - 1) / (4 * rows), g.batch);
     const uint8_t *src = level == 1 ? b.l0.ptr : b.pyr + S.off;
     const long long sfs = level == 1 ? b.l0.fstride : (long long)g.slab;
     const int spitch = level == 1 ? b.l0.pitch : S.pitch;
     // a frame's own rows at level 0 (the caller's buffer ends there); lower levels sit inside the slab,
     // which has slack behind its last level
     const uint32_t src_bytes = (uint32_t)spitch * (uint32_t)S.h + (level == 1 ? 0u : 16u);
-    k_resize<<<grid, 256, 0, s>>>(src, sfs, src_bytes, b.pyr, g.slab, spitch, D.off, D.pitch, D.w, D.h,
-                                  b.xtab + D.xtab_off, b.ytab + D.ytab_off);
+    if (rows == RS_ROWS)
+        k_resize<RS_ROWS><<<grid, 256, 0, s>>>(src, sfs, src_bytes, b.pyr, g.slab, spitch, D.off, D.pitch, D.w, D.h,
+                                               b.xtab + D.xtab_off, b.ytab + D.ytab_off);
+    else
+        k_resize<RS2_ROWS><<<grid, 256, 0, s>>>(src, sfs, src_bytes, b.pyr, g.slab, spitch, D.off, D.pitch, D.w, D.h,
+                                                b.xtab + D.xtab_off, b.ytab + D.ytab_off);
     return hipGetLastError();
 }
