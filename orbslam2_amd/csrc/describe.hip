@@ -266,11 +266,14 @@ struct DescArgs {
 };
 
 // Keypoints per wave, one after the other (the next one's window in flight while the current one is computed).
-// A frame's 2000 keypoints then spread over 125 workgroups instead of 32, so fewer frames are in flight on an
-// XCD at a time and more of a frame's window rows are still in its L2 when the next keypoint wants them:
-// 16 -> 4 took the kernel from 0.088 to 0.075 ms per 64 KITTI frames (8: 0.077, 2: 0.083).
+// With few keypoints per wave a frame's 2000 keypoints spread over more workgroups (125 at 4 per wave, 32 at 16),
+// so fewer frames are in flight on an XCD at a time and more of a frame's window rows are still in its L2 when the
+// next keypoint wants them: 16 -> 4 took the kernel from 0.088 to 0.075 ms per 64 KITTI frames (8: 0.077, 2: 0.083).  With the later, leaner
+// keypoint loops the per-workgroup set-up (weights, test table, keypoint records) weighs more: per 256 frames
+// 4: 0.2945 ms, 6: 0.286, 8: 0.287, 10: 0.291, 12: 0.294, 16: 0.299; in a batch 8 .. 12 give 2 % more frames/s
+// than 4, 16 gives 5 % fewer.
 #ifndef DESC_KPW
-#define DESC_KPW 4
+#define DESC_KPW 8
 #endif
 #define DESC_SLOTS (4 * DESC_KPW)  // keypoint slots per workgroup
 #define PAT_ROWS 31    // orientation patch: rows y-15 .. y+15
