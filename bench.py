@@ -108,10 +108,19 @@ def main():
     ap.add_argument("--pcie-only", action="store_true", help="only the host-memory-to-host-memory measurement")
     ap.add_argument("--pcie-instances", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="the extractor instances run on independent streams instead of taking turns in one "
+                         "orbx_pipeline (comparison runs)")
+    ap.add_argument("--hw-queues", type=int, default=8,
+                    help="GPU_MAX_HW_QUEUES for this process unless the environment already asks for more (HIP's "
+                         "default of 4 makes the instances' streams share hardware queues); 0: leave it")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: the ranks only form the process group, pass the barriers and the reductions of "
                          "the timed region and rank 0 prints a line with value null (checks the launch on a CPU box)")
     args = ap.parse_args()
+    # before anything starts the HIP runtime (the ranks started below inherit it)
+    if args.hw_queues and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < args.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # Called without a launcher: this process has not touched the GPU (nothing above imports torch), so it
@@ -192,8 +201,12 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(ninst)]
     exs = [orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=half, device=local_rank)
            for _ in range(ninst)]
+    # the instances take turns: each one's blur runs behind the work of the instance called before it
+    pipeline = None if (args.exclusive or args.no_pipeline or ninst < 2) else orbx.Pipeline(local_rank)
     for e, st in zip(exs, streams):
         e.set_stream(st.cuda_stream)
+        if pipeline is not None:
+            e.set_pipeline(pipeline)
     stream = streams[0]
     ex = exs[0]
     nwin = nres // batch  # windows of `batch` frames; step s works on window s % nwin
@@ -303,7 +316,10 @@ def main():
         "stages_ms_per_launch_exclusive": {k: round(v, 4) for k, v in stage_ms.items()},
         "frames_per_launch": launch_frames,
         "timed_region": "exclusive (1 instance, serialised stages)" if args.exclusive else
-                        "%d instances on %d streams, blur overlapped" % (ninst, 2 * ninst),
+                        ("%d instances taking turns in one orbx_pipeline: one stream each, an instance's blur behind "
+                         "the work of the instance before it" % ninst) if pipeline is not None else
+                        "%d instances on %d independent streams, blur overlapped" % (ninst, 2 * ninst),
+        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
     }
 
     if not args.no_config5:

@@ -5,7 +5,7 @@
 liborbx.so (hand-written HIP kernels for gfx950).
 """
 from ._lib import KEYPOINT_DTYPE, OrbxError, lib  # noqa: F401
-from .extractor import ORBextractor, synth_image  # noqa: F401
+from .extractor import ORBextractor, Pipeline, synth_image  # noqa: F401
 from .matcher import ORBmatcher, synth_descriptors  # noqa: F401
 from .stereo import ComputeStereoMatches, compute_stereo_matches_device  # noqa: F401
 from .vocabulary import ORBVocabulary  # noqa: F401

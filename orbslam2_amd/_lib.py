@@ -51,6 +51,9 @@ SIGNATURES = {
     "orbx_extractor_create": (C.c_int, [C.POINTER(Params), C.POINTER(_P)]),
     "orbx_extractor_destroy": (None, [_P]),
     "orbx_extractor_set_stream": (C.c_int, [_P, _P]),
+    "orbx_pipeline_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "orbx_pipeline_destroy": (None, [_P]),
+    "orbx_extractor_set_pipeline": (C.c_int, [_P, _P]),
     "orbx_extractor_levels": (C.c_int, [_P]),
     "orbx_extractor_scale_tables": (C.c_int, [_P, _f32p, _f32p, _f32p, _f32p]),
     "orbx_extractor_features_per_level": (C.c_int, [_P, _i32p]),

@@ -28,6 +28,20 @@ inline void check(int rc, const char *where)
 // data pointer of an optional array: null when the vector is empty
 template <typename T> inline const T *opt(const std::vector<T> &v) { return v.empty() ? nullptr : v.data(); }
 
+// Extractor objects of one device that take turns on batches (orbx_pipeline_create): attach each with
+// Extractor::set_pipeline; destroy it after them.
+class Pipeline {
+public:
+    explicit Pipeline(int device = 0) { check(orbx_pipeline_create(device, &h_), "orbx_pipeline_create"); }
+    ~Pipeline() { orbx_pipeline_destroy(h_); }
+    Pipeline(const Pipeline &) = delete;
+    Pipeline &operator=(const Pipeline &) = delete;
+    orbx_pipeline *handle() const { return h_; }
+
+private:
+    orbx_pipeline *h_ = nullptr;
+};
+
 class Extractor {
 public:
     Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int max_width = 1920,
@@ -43,6 +57,7 @@ public:
         cap_ = orbx_extractor_max_keypoints(h_);
     }
     ~Extractor() { orbx_extractor_destroy(h_); }
+    void set_pipeline(const Pipeline *p) { check(orbx_extractor_set_pipeline(h_, p ? p->handle() : nullptr), "set_pipeline"); }
     Extractor(const Extractor &) = delete;
     Extractor &operator=(const Extractor &) = delete;
 

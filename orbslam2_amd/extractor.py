@@ -16,6 +16,28 @@ def synth_image(seed, width, height, variant=0, stride=None):
     return img
 
 
+class Pipeline:
+    """Extractor handles of one device that take turns on batches (orbx_pipeline_create): see
+    ORBextractor.set_pipeline.  GPU_MAX_HW_QUEUES should be 8 or more before the first HIP call."""
+
+    def __init__(self, device=0):
+        self._lib = L.lib()
+        h = C.c_void_p()
+        L.check(self._lib.orbx_pipeline_create(int(device), C.byref(h)), "orbx_pipeline_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.orbx_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ORBextractor:
     """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
     (constructor src/ORBextractor.cc:432-506).  Extra keyword arguments size the device workspace."""
@@ -80,6 +102,13 @@ class ORBextractor:
 
     def set_stream(self, hip_stream):
         L.check(self._lib.orbx_extractor_set_stream(self._h, C.c_void_p(hip_stream)), "orbx_extractor_set_stream")
+
+    def set_pipeline(self, pipeline):
+        """Attaches the handle to `pipeline` (a Pipeline shared by the handles of one device that take turns on
+        batches: orbx_extractor_set_pipeline); None detaches."""
+        L.check(self._lib.orbx_extractor_set_pipeline(self._h, pipeline._h if pipeline is not None else None),
+                "orbx_extractor_set_pipeline")
+        self._pipeline = pipeline  # keeps it alive as long as the handle uses it
 
     # ---- operator() (src/ORBextractor.cc:1114-1182) ----
     def __call__(self, image, mask=None, pyramid_border=None):

@@ -242,6 +242,55 @@ def test_device_batch_in_place_and_copied(oracle, stride):
             assert np.array_equal(got, ex.pyramid_level(2, l, border)), (border, l)
 
 
+def test_handles_taking_turns_in_a_pipeline(oracle):
+    """Three handles attached to one pipeline, each with a stream of its own, called round robin (a handle's blur is
+    enqueued on the stream of the handle called before it): every batch equals the oracle, also when a handle is
+    destroyed or detached in between and when the batch is too small to take part."""
+    import torch
+    w, h, B = 752, 480, 6
+    host = np.zeros((3, B, h, w), np.uint8)
+    for i in range(3):
+        for f in range(B):
+            host[i, f] = orbx.synth_image(SEED + 1000 * i + 7 * f, w, h, 0)
+    dev = torch.from_numpy(host).cuda()
+    want = [[oracle_extract(oracle, host[i, f], EUROC_STEREO) for f in range(B)] for i in range(3)]
+    pipe = orbx.Pipeline(0)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    exs = [make_extractor(EUROC_STEREO, w, h, batch=B) for _ in range(3)]
+    for e, st in zip(exs, streams):
+        e.set_stream(st.cuda_stream)
+        e.set_pipeline(pipe)
+
+    def check(i, nframes=B):
+        n, _ = exs[i].batch_counts()
+        for f in range(nframes):
+            kg, dg = exs[i].batch_download(f)
+            assert n[f] == len(want[i][f][0])
+            compare_frame(kg, dg, *want[i][f])
+
+    for rnd in range(3):  # the rounds run ahead of each other on the device: nothing waits in between
+        for i in range(3):
+            exs[i].extract_batch_device(dev[i].data_ptr(), B, w, h, w, h * w)
+    for i in range(3):
+        check(i)
+    # a batch of four frames or fewer does not take part (and does not become the predecessor)
+    exs[1].extract_batch_device(dev[1].data_ptr(), 3, w, h, w, h * w)
+    exs[2].extract_batch_device(dev[2].data_ptr(), B, w, h, w, h * w)
+    check(1, 3)
+    check(2)
+    # the predecessor goes away: the next handle falls back to its own second stream once
+    exs[2].close()
+    exs[0].extract_batch_device(dev[0].data_ptr(), B, w, h, w, h * w)
+    exs[1].set_pipeline(None)
+    exs[1].extract_batch_device(dev[1].data_ptr(), B, w, h, w, h * w)
+    exs[0].extract_batch_device(dev[0].data_ptr(), B, w, h, w, h * w)
+    check(0)
+    check(1)
+    for e in exs[:2]:
+        e.close()
+    pipe.close()
+
+
 def test_gpu_reproduces_golden_fixtures():
     """The committed fixtures (tests/golden, written by tests/golden/make_golden.py from the oracle)."""
     import glob
