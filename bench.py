@@ -119,6 +119,7 @@ def main():
                          "the timed region and rank 0 prints a line with value null (checks the launch on a CPU box)")
     args = ap.parse_args()
     # before anything starts the HIP runtime (the ranks started below inherit it)
+    env_before = dict(os.environ)
     if args.hw_queues and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < args.hw_queues:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
 
@@ -140,6 +141,13 @@ def main():
     dist_path = world > 1 or os.environ.get("ORBX_BENCH_FORCE_DIST") == "1"
     backend = os.environ.get("ORBX_BENCH_BACKEND", "nccl")  # "gloo" rehearses the N>1 path on one GPU
     share_gpu = os.environ.get("ORBX_BENCH_SHARE_GPU") == "1"  # rehearsal: more ranks than GPUs, ranks share devices
+    # The host-memory measurement (rank 0's own business) runs in a process of its own, started here, before
+    # this one touches the GPU: its two instances want the streams of a fresh process on HIP's default number of
+    # hardware queues (104 k frames/s; 46-66 k inside this process, after or beside the streams of the main
+    # measurement or with 8 queues).  The other ranks meanwhile wait at the first barrier.
+    pcie_first = None
+    if not args.no_pcie and not args.pcie_only and not args.dry_run and rank == 0:
+        pcie_first = pcie_in_child(args, env_before, local_rank)
     import torch
     import torch.distributed as dist
 
@@ -184,13 +192,6 @@ def main():
     if args.pcie_only:
         print(json.dumps(pcie_inclusive(orbx, torch, host, w, h, nfeat, local_rank, instances=args.pcie_instances)))
         return
-    # The host-memory measurement (rank 0's own business) comes first: its two instances then get hardware
-    # queues of their own.  After the streams of the main measurement have existed (even closed), their streams
-    # share queues and upload and extraction of the two instances no longer overlap (46-59 k instead of 100 k
-    # frames/s).  The other ranks meanwhile wait at the first barrier.
-    pcie_first = None
-    if not args.no_pcie and rank == 0:
-        pcie_first = pcie_inclusive(orbx, torch, host, w, h, nfeat, local_rank, instances=args.pcie_instances)
     frames = torch.from_numpy(host).cuda()
     # A stereo pair batch: left and right images go through separate extractor instances on separate
     # streams, as the reference runs mpORBextractorLeft / mpORBextractorRight in two threads
@@ -648,6 +649,24 @@ def bench_hamming_sharded(orbx, torch, dist, stream, rank, world, coll_dev):
             "roofline": {"bound": "mfma", "dtype": "fp4", "achieved": round(rate * MAC_PER_PAIR * 2 / 1e12 / world, 1),
                          "peak": round(MFMA_F4_MAC_PER_S * 2 / 1e12, 1), "unit": "TFLOP/s per GPU",
                          "frac": round(rate / world * MAC_PER_PAIR / MFMA_F4_MAC_PER_S, 4)}}
+
+
+def pcie_in_child(args, env, local_rank):
+    """`bench.py --pcie-only` as a child process with the caller's original environment (no launcher variables, so
+    it is a one-rank run on this rank's GPU); returns its JSON object, or an error entry."""
+    import subprocess
+    env = {k: v for k, v in env.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT")
+           and not k.startswith("TORCHELASTIC")}
+    env["LOCAL_RANK"] = str(local_rank)
+    cmd = [sys.executable, os.path.abspath(__file__), "--pcie-only", "--gpus", "1", "--workload", args.workload,
+           "--pcie-instances", str(args.pcie_instances), "--batch", "256", "--frames-resident", "256", "--hw-queues", "0"]
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, check=True)
+        line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # the headline does not depend on it
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
 
 def pcie_inclusive(orbx, torch, host, w, h, nfeat, device, batch=64, instances=2, rounds=24):
