@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     }
 }
 
-// part 0: clear the per-cell flags and the candidate counts, 1: detection
+// part 0: clear the status words, the candidate counts and the per-cell flags, 1: detection
 hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s, int part)
 {
     FastArgs a;
@@ -422,9 +422,9 @@ hipError_t orbx_launch_fast(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t
     }
     a.tile_base[g.nlevels] = g.ftiles_per_frame;
     if (part == 0) {
-        // the flags lie behind the counts in one allocation: one fill
-        const uint8_t *lo = reinterpret_cast<const uint8_t *>(b.ncand);
-        return hipMemsetAsync(b.ncand, 0, (size_t)(b.cell_flag - lo) + (size_t)g.batch * g.cells_per_frame, s);
+        // the counts lie behind the status words and the flags behind the counts in one allocation: one fill
+        const uint8_t *lo = reinterpret_cast<const uint8_t *>(b.status);
+        return hipMemsetAsync(b.status, 0, (size_t)(b.cell_flag - lo) + (size_t)g.batch * g.cells_per_frame, s);
     }
     const dim3 grid = orbx_frame_grid(g.ftiles_per_frame, g.batch);
     k_fast<<<grid, 256, 0, s>>>(b.pyr, b.ncand, b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.status,

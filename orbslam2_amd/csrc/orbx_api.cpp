@@ -327,8 +327,8 @@ template <typename T> static hipError_t dmalloc(T **p, size_t n)
 static void free_buffers(orbx_extractor *ex)
 {
     OrbxBuffers &b = ex->buf;
-    void *ptrs[] = {b.pyr,       b.blur,    b.ncand /* and cell_flag */, b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
-                    b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n,   ex->d_ptab, ex->d_xtab,
+    void *ptrs[] = {b.pyr,       b.blur,    b.cand_xy, b.cand_resp, b.cand_key, b.cand_node,
+                    b.kept_xy,   b.kept_resp, b.nkept,   b.out_kp, b.out_n /* and status, ncand, cell_flag */, ex->d_ptab, ex->d_xtab,
                     ex->d_ytab,  ex->d_tiletab, ex->d_blur_bands};
     for (void *p : ptrs)
         if (p)
@@ -427,12 +427,16 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     // 256 bytes of slack: window copies read whole words that may run past the last row
     if (e == hipSuccess) e = dmalloc(&b.pyr, B * g.slab + 256);
     if (e == hipSuccess) e = dmalloc(&b.blur, B * g.bslab + 256);
-    // candidate counts and per-cell flags in one allocation (counts first): one fill clears both before detection
+    // One allocation: keypoint counts | status words | candidate counts | per-cell flags.  The counts and the
+    // status words are neighbours for the single-frame fetch (one copy); the status words, the candidate counts and
+    // the flags are neighbours so that one fill clears them before detection.
     if (e == hipSuccess) {
-        uint8_t *both = nullptr;
-        e = dmalloc(&both, B * g.nlevels * sizeof(int) + B * g.cells_per_frame);
-        b.ncand = reinterpret_cast<int *>(both);
-        b.cell_flag = both ? both + B * g.nlevels * sizeof(int) : nullptr;
+        uint8_t *all = nullptr;
+        e = dmalloc(&all, (B + ORBX_ST_COUNT + B * g.nlevels) * sizeof(int) + B * g.cells_per_frame);
+        b.out_n = reinterpret_cast<int *>(all);
+        b.status = all ? b.out_n + B : nullptr;
+        b.ncand = all ? b.status + ORBX_ST_COUNT : nullptr;
+        b.cell_flag = all ? reinterpret_cast<uint8_t *>(b.ncand + B * g.nlevels) : nullptr;
     }
     if (e == hipSuccess) e = dmalloc(&b.cand_xy, B * g.cand_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.cand_resp, B * g.cand_per_frame);
@@ -441,8 +445,8 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
     if (e == hipSuccess) e = dmalloc(&b.kept_xy, B * g.kp_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.kept_resp, B * g.kp_per_frame);
     if (e == hipSuccess) e = dmalloc(&b.nkept, B * g.nlevels);
-    // The descriptors lie behind the keypoint records and the status words behind the counts, each pair in one
-    // allocation: a handle for single frames (max_batch 1) then fetches a frame's results with two copies, not four.
+    // The descriptors lie behind the keypoint records in one allocation (as the status words behind the counts,
+    // above): a handle for single frames (max_batch 1) then fetches a frame's results with two copies, not four.
     // (out_cap is a multiple of 4, so the descriptor rows start 16-byte aligned.)
     if (e == hipSuccess) {
         uint8_t *both = nullptr;
@@ -450,8 +454,6 @@ extern "C" int orbx_extractor_create(const orbx_params *params, orbx_extractor *
         b.out_kp = reinterpret_cast<orbx_keypoint *>(both);
         b.out_desc = both ? both + B * g.out_cap * sizeof(orbx_keypoint) : nullptr;
     }
-    if (e == hipSuccess) e = dmalloc(&b.out_n, B + ORBX_ST_COUNT);
-    b.status = b.out_n ? b.out_n + B : nullptr;
     int xt = 0, yt = 0;
     for (int l = 0; l < g.nlevels; l++)
         xt += align_up(g.lv[l].w, 4), yt += align_up(g.lv[l].h, 2);
@@ -669,8 +671,7 @@ static int run_pipeline(orbx_extractor *ex)
             s2 = ex->pipe->last_stream;
         ex->pipe->last_stream = s;
     }
-    HIP_TRY(hipMemsetAsync(b.status, 0, ORBX_ST_COUNT * sizeof(int), s));
-    HIP_TRY(orbx_launch_fast(g, b, s, 0));
+    HIP_TRY(orbx_launch_fast(g, b, s, 0));  // clears the status words too
     HIP_TRY(prof_mark(ex, 1, 0, s));
     // A few frames: pairs of levels in one launch (four launches instead of seven; the time of such a call is
     // mostly launches).  Batches: a launch per level, which is faster there (the fused kernel computes 5 % of
