@@ -538,26 +538,48 @@ def bench_config5(orbx, torch, dist, rank, world, w, h, nfeat, block, stride, co
         host[block, :, :w] = canvas(rank + 1, block)[:, :w]
     dev = torch.from_numpy(host).cuda()
     torch.cuda.synchronize()
-    st = torch.cuda.Stream()  # extractor and matcher share one real stream (the null stream would give each its own)
-    ex = orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=nfr,
-                           device=torch.cuda.current_device())
-    ex.set_stream(st.cuda_stream)
-    m = orbx.ORBmatcher(0.9, True, device=torch.cuda.current_device())
-    m.set_stream(st.cuda_stream)
-    ex.extract_batch_device(dev.data_ptr(), nfr, w, h, stride, h * stride)
-    d_kp, d_desc, d_cnt, cap = ex.device_results()
     npair = pair_hi - lo
-    m12 = torch.zeros((max(npair, 1), cap), dtype=torch.int32, device="cuda")
-    nm = torch.zeros(max(npair, 1), dtype=torch.int32, device="cuda")
-    npd = torch.zeros(max(npair, 1), dtype=torch.int32, device="cuda")
+    # The rank's pairs are cut into two contiguous chunks, each with an extractor and a matcher of its own on one
+    # stream: a chunk extracts its frames plus the first frame of the next chunk (the same halo rule one level down:
+    # one frame of 1024 is extracted twice) and matches its own pairs; the extractors take turns in one
+    # orbx_pipeline and nothing crosses between the chunks.  Chunks 1 / 2 / 3 / 4 / 8: 175 / 186 / 164 / 178 / 145 k
+    # frames/s (the matcher's workgroups want most of a compute unit's LDS and wait for the extraction kernels of
+    # the other chunks to drain: more chunks, more waiting).  ORBX_BENCH_C5_CHAINS: comparison runs.
+    nchain = int(os.environ.get("ORBX_BENCH_C5_CHAINS", "2"))
+    nchain = max(1, min(nchain, npair))
+    cuts = [npair * c // nchain for c in range(nchain + 1)]
     bounds = (0.0, float(w), 0.0, float(h))
+    pipeline = orbx.Pipeline(torch.cuda.current_device()) if nchain > 1 else None
+    chains = []
+    for c in range(nchain):
+        p0, p1 = cuts[c], cuts[c + 1]
+        f0, f1 = (p0, p1 + 1) if npair > 0 else (0, nfr)  # frames p0 .. p1 hold pairs p0 .. p1-1
+        st = torch.cuda.Stream()  # extractor and matcher share one real stream (the null stream would give each its own)
+        ex = orbx.ORBextractor(nfeat, 1.2, 8, 20, 7, max_width=w, max_height=h, max_batch=f1 - f0,
+                               device=torch.cuda.current_device())
+        ex.set_stream(st.cuda_stream)
+        if pipeline is not None:
+            ex.set_pipeline(pipeline)
+        m = orbx.ORBmatcher(0.9, True, device=torch.cuda.current_device())
+        m.set_stream(st.cuda_stream)
+        src = dev.data_ptr() + f0 * h * stride
+        ex.extract_batch_device(src, f1 - f0, w, h, stride, h * stride)
+        d_kp, d_desc, d_cnt, cap = ex.device_results()
+        np_c = p1 - p0
+        chains.append({"ex": ex, "m": m, "st": st, "src": src, "nfr": f1 - f0, "npair": np_c, "res": (d_kp, d_desc, d_cnt, cap),
+                       "m12": torch.zeros((max(np_c, 1), cap), dtype=torch.int32, device="cuda"),
+                       "nm": torch.zeros(max(np_c, 1), dtype=torch.int32, device="cuda"),
+                       "npd": torch.zeros(max(np_c, 1), dtype=torch.int32, device="cuda")})
 
     def run():
-        ex.extract_batch_device(dev.data_ptr(), nfr, w, h, stride, h * stride)
-        if npair > 0:
-            # frames lo .. lo+npair are the first npair+1 of the batch: pairs (i, i+1), i < npair
-            m.search_for_initialization_batch_device(d_kp, d_desc, d_cnt, cap, npair + 1, 600, bounds, m12.data_ptr(),
-                                                     nm.data_ptr(), npd.data_ptr(), windowSize=100)
+        for ch in chains:
+            ch["ex"].extract_batch_device(ch["src"], ch["nfr"], w, h, stride, h * stride)
+            if ch["npair"] > 0:
+                d_kp, d_desc, d_cnt, cap = ch["res"]
+                # the chunk's frames are pairs (i, i+1), i < npair, of its own batch
+                ch["m"].search_for_initialization_batch_device(d_kp, d_desc, d_cnt, cap, ch["npair"] + 1, 600, bounds,
+                                                               ch["m12"].data_ptr(), ch["nm"].data_ptr(),
+                                                               ch["npd"].data_ptr(), windowSize=100)
 
     for _ in range(2):
         run()
@@ -570,15 +592,18 @@ def bench_config5(orbx, torch, dist, rank, world, w, h, nfeat, block, stride, co
         run()
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_dev)
-    tot = torch.tensor([float(npair), float(nm.sum().item()), float(npd.sum().item()), float(nfr)], dtype=torch.float64,
+    nmatch = sum(float(ch["nm"][:ch["npair"]].sum().item()) for ch in chains)
+    ndist = sum(float(ch["npd"][:ch["npair"]].sum().item()) for ch in chains)
+    tot = torch.tensor([float(npair), nmatch, ndist, float(sum(ch["nfr"] for ch in chains))], dtype=torch.float64,
                        device=coll_dev)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     sec = float(el.item()) / reps
     pairs, matches, dists, extracted = [float(v) for v in tot.tolist()]
-    ex.close()
-    return {"frames": n, "frame_pairs": int(pairs), "frames_extracted_incl_halo": int(extracted),
+    for ch in chains:
+        ch["ex"].close()
+    return {"frames": n, "frame_pairs": int(pairs), "frames_extracted_incl_halo": int(extracted), "chains_per_gpu": nchain,
             "frames_per_s": round(n / sec, 1), "candidate_pair_distances_per_s": round(dists / sec, 1),
             "mean_matches_per_pair": round(matches / max(pairs, 1), 1), "ms_per_pass": round(sec * 1e3, 3),
             "sharding": "contiguous frame blocks, 1-frame halo re-extracted by the owner of the pair, no collective"}
