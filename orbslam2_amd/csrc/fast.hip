@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     __shared__ uint16_t queue[QUEUE_CAP];
     __shared__ int qn, sn, cn;
 
+    FAST_CUT(-1);
     const int f = ORBX_BLOCK_FRAME, unit = ORBX_BLOCK_UNIT;
     if (f >= a.batch)
         return;

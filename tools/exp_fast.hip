@@ -113,11 +113,13 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const char *names[] = {"cut before staging (empty)", "cut after staging", "cut after compass test + queue",
-                           "cut after arc score", "whole kernel"};
-    float t[5];
-    long long found[5];
-    for (int cut = 0; cut <= 4; cut++) {
+    const char *names[] = {"cut at the first statement", "cut before staging (tile found)", "cut after staging",
+                           "cut after compass test + queue", "cut after arc score", "whole kernel"};
+    float tt[6];
+    long long ff[6];
+    float *t = tt + 1;
+    long long *found = ff + 1;
+    for (int cut = -1; cut <= 4; cut++) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_cut), &cut, 4));
         for (int r = 0; r < 3; r++)
             k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_xy, d_resp, d_key, d_flag, d_status, d_tab, a);
@@ -138,8 +140,8 @@ int main(int argc, char **argv)
             found[cut] += c;
     }
     printf("%d frames, %d tiles per frame\n", B, tiles);
-    for (int cut = 0; cut <= 4; cut++)
-        printf("  %-34s %.4f ms   (%.1f candidates per frame)\n", names[cut], t[cut], (double)found[cut] / B);
+    for (int cut = -1; cut <= 4; cut++)
+        printf("  %-34s %.4f ms   (%.1f candidates per frame)\n", names[cut + 1], t[cut], (double)found[cut] / B);
     orbx_extractor_destroy(ex);
     return 0;
 }
