@@ -26,6 +26,7 @@ struct OctLevel {
 struct OctArgs {
     int nlevels, cand_per_frame, kp_per_frame, cells_per_frame;
     int t_ini, t_min;  // FAST thresholds clamped to [1,255]
+    int level0;        // first level of this launch (blockIdx.x counts from it)
     OctLevel lv[ORBX_MAX_LEVELS];
 };
 
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                 uint8_t *__restrict__ kept_resp, int *__restrict__ nkept,
                                                 int *__restrict__ status, OctArgs a)
 {
-    const int lvl = blockIdx.x, f = blockIdx.y;
+    const int lvl = blockIdx.x + a.level0, f = blockIdx.y;
     const OctLevel &L = a.lv[lvl];
     const size_t cb = (size_t)f * a.cand_per_frame + L.cand_base;
     const size_t kb = (size_t)f * a.kp_per_frame + L.kp_base;
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream_t s)
 {
     OctArgs a;
+    a.level0 = 0;
     a.nlevels = g.nlevels, a.cand_per_frame = g.cand_per_frame, a.kp_per_frame = g.kp_per_frame;
     a.cells_per_frame = g.cells_per_frame;
     a.t_ini = min(max(g.ini_th, 1), 255), a.t_min = min(max(g.min_th, 1), 255);
@@ -565,20 +567,38 @@ hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream
         a.lv[l].hx = L.hx;
         cap = L.node_cap > cap ? L.node_cap : cap;
     }
-    // every level carves its own node_cap out of an allocation sized for the largest level
-    const size_t lds = orbx_octree_lds_bytes(cap);
-    auto launch = [&](auto kernel, int nt) -> hipError_t {
+    // every level carves its own node_cap out of an allocation sized for the largest level of its launch
+    auto launch = [&](auto kernel, int nt, int l0, int l1) -> hipError_t {
+        int c = 1;
+        for (int l = l0; l < l1; l++)
+            c = max(c, g.lv[l].node_cap);
+        const size_t lds = orbx_octree_lds_bytes(c);
         if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess)
                 return e;
         }
-        kernel<<<dim3(g.nlevels, g.batch), nt, lds, s>>>(b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.cand_node,
-                                                         b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status, a);
+        a.level0 = l0;
+        kernel<<<dim3(l1 - l0, g.batch), nt, lds, s>>>(b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.cand_node,
+                                                       b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status, a);
         return hipGetLastError();
     };
-    return launch(k_octree<OCT_NT, OCT_KMAX>, OCT_NT);
+    (void)cap;
+    // Batches: the levels whose arrays need more LDS than a workgroup of the detection kernel holds (20 KB: KITTI
+    // levels 0 and 1 with 28 and 23 KB) go in a launch of their own, the others in a second one that reserves only
+    // what its largest level needs.  Beside the kernels of the other handles a workgroup of this kernel has to wait
+    // for that much free LDS on one compute unit, and the detection kernel frees it 20 KB at a time: with one launch
+    // sized for level 0 the kernel takes 0.65 ms instead of 0.105 there.  Two launches are slower alone (0.119 ms) and
+    // give 1.5 % more frames/s in the batch; three or more launches give no more.
+    int split = 0;
+    while (split < g.nlevels && orbx_octree_lds_bytes(g.lv[split].node_cap) > 20 * 1024)
+        split++;
+    if (g.batch > 4 && split > 0 && split < g.nlevels) {
+        const hipError_t e = launch(k_octree<OCT_NT, OCT_KMAX>, OCT_NT, 0, split);
+        return e != hipSuccess ? e : launch(k_octree<OCT_NT, OCT_KMAX>, OCT_NT, split, g.nlevels);
+    }
+    return launch(k_octree<OCT_NT, OCT_KMAX>, OCT_NT, 0, g.nlevels);
 }
 
 template <int NT>
