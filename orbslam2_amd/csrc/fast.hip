@@ -76,8 +76,26 @@ __device__ __forceinline__ uint32_t compass4(uint32_t vw, uint32_t r0w, uint32_t
     return dark | bright;
 }
 
-// t points at the centre byte of the staged tile.  Ring bytes are widened to p | (255-p)<<16:
-// max over a 9-arc of the low halves = brightest ring pixel of the arc, of the high halves =
+// Three-input packed maximum / minimum.  The chip has them for half-precision floats only; the values here are
+// 0x400 + (0 .. 255) in each half, i.e. positive normal half-precision numbers, whose order is the order of their
+// bit patterns, so the float instructions compute the integer result.
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+#define ARC_BIAS 0x400  // added to both halves of a widened ring pixel (see pk_max3)
+
+// t points at the centre byte of the staged tile.  Ring bytes are widened to p | (255-p)<<16 (plus ARC_BIAS in
+// both halves): max over a 9-arc of the low halves = brightest ring pixel of the arc, of the high halves =
 // 255 - darkest.  Both polarities at once:
 //   dark   (ring < v):  max_arcs min(v - ring) = v - min_arcs max_9(ring)
 //   bright (ring > v):  max_arcs min(ring - v) = (255 - min_arcs max_9(255 - ring)) - v
@@ -101,29 +119,28 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
     d[13] = t[p - 3];
     d[14] = t[2 * p - 2];
     d[15] = t[3 * p - 1];
-    // p -> p | (255-p) << 16 in one 24-bit multiply-add: p * (1 - 65536) + (255 << 16)
+    // p -> p | (255-p) << 16, biased, in one 24-bit multiply-add: p * (1 - 65536) + (255 << 16) + bias
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        d[k] = (uint32_t)(__mul24((int)d[k], -65535) + 0x00ff0000);
+        d[k] = (uint32_t)(__mul24((int)d[k], -65535) + (0x00ff0000 + ARC_BIAS * 0x10001));
     // Arc k holds ring pixels k .. k+8.  Arcs k and k-1 share the eight pixels k .. k+7, so
     //   min(max_arc(k), max_arc(k-1)) = max(max8(k), min(d[k+8], d[k-1]))
-    // and the even k cover all sixteen arcs: the eight-pixel maxima are needed at even k only.
-    uint32_t m2[8], m4[8];
+    // and the even k cover all sixteen arcs: the eight-pixel maxima are needed at even k only, and each joins
+    // the minimum of its two outer pixels in one three-input maximum of two four-pixel maxima and that minimum.
+    uint32_t m2[8], m4[8], x[8];
 #pragma unroll
     for (int k = 0; k < 8; k++)
         m2[k] = pk_max(d[2 * k], d[2 * k + 1]);
 #pragma unroll
     for (int k = 0; k < 8; k++)
         m4[k] = pk_max(m2[k], m2[(k + 1) & 7]);
-    uint32_t best = 0xffffffffu;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint32_t m8 = pk_max(m4[k], m4[(k + 2) & 7]);  // pixels 2k .. 2k+7
-        best = pk_min(best, pk_max(m8, pk_min(d[(2 * k + 8) & 15], d[(2 * k + 15) & 15])));
-    }
+    for (int k = 0; k < 8; k++)  // pixels 2k .. 2k+7 and the outer pair
+        x[k] = pk_max3(m4[k], m4[(k + 2) & 7], pk_min(d[(2 * k + 8) & 15], d[(2 * k + 15) & 15]));
+    const uint32_t best = pk_min(pk_min3(pk_min3(x[0], x[1], x[2]), x[3], x[4]), pk_min3(x[5], x[6], x[7]));
     const int v = t[0];
-    const int dark = v - (int)(best & 0xffff);
-    const int bright = 255 - (int)(best >> 16) - v;
+    const int dark = v + ARC_BIAS - (int)(best & 0xffff);
+    const int bright = 255 + ARC_BIAS - (int)(best >> 16) - v;
     return max(dark, bright);
 }
 
