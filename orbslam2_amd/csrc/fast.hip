@@ -18,7 +18,9 @@
 // Work per 64x64 tile:  stage the image tile (+4 px) in LDS; test every pixel of the tile (+1 px
 // ring) against the four compass points, two pixels per packed 16-bit operation (a 9-arc contains at
 // least one pixel of each antipodal pair); queue the few that pass; compute A only for those, both
-// polarities at once with packed 16-bit min/max; suppress non-maxima; append to the level's candidate arrays.
+// polarities at once with packed 16-bit min/max (half-precision instructions on values whose float order is their
+// integer order: they have three-input forms and operand modifiers that widen the bytes for free); suppress
+// non-maxima; append to the level's candidate arrays.
 #include "orbx_internal.h"
 
 #ifndef FAST_CUT
@@ -37,19 +39,6 @@
 #define SC_P 72                  // bytes per row of the score map: staged columns 12 .. 83 (the 18 words that matter)
 #define SC_AT(r, c) (((r) - 3) * SC_P + (c) - 4 * GRP_0)  // score of staged row r (3 .. 68), staged column c
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef short i16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
-{
-    const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
-{
-    const u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
-    return __builtin_bit_cast(uint32_t, r);
-}
 // Compass test of four pixels at once, one per byte, on pixel values halved to 7 bits (the eighth bit of
 // every byte is the room the comparisons need).  A 9-arc holds at least one pixel of each antipodal pair,
 // so a corner at threshold t needs a ring pixel r with r < v - t in both compass pairs (dark arc) or with
@@ -76,29 +65,55 @@ __device__ __forceinline__ uint32_t compass4(uint32_t vw, uint32_t r0w, uint32_t
     return dark | bright;
 }
 
-// Three-input packed maximum / minimum.  The chip has them for half-precision floats only; the values here are
-// 0x400 + (0 .. 255) in each half, i.e. positive normal half-precision numbers, whose order is the order of their
-// bit patterns, so the float instructions compute the integer result.
-__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
+// Packed maximum / minimum of the arc score.  A register holds a value in 0 .. 255 in its low half and the
+// NEGATED value of another quantity in its high half (sign bit | value), both read as half-precision floats:
+// the bit patterns 0x0000 .. 0x00ff are +0 and the smallest subnormal numbers, ordered like the integers they
+// spell, and 0x8000 | x is -x, so a maximum of the high halves is minus the minimum of the values (the kernel runs
+// with subnormal numbers kept, the compiler's setting for this chip).  The chip has three-input packed maximum /
+// minimum for this type only.
+__device__ __forceinline__ uint32_t pkf_max(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pkf_min(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pkf_max3(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t d;
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
-__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
+__device__ __forceinline__ uint32_t pkf_min3(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t d;
     asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// From two plain bytes (low halves): max(a, b) | -min(a, b) << 16 and min(a, b) | -max(a, b) << 16.  Both halves
+// of the result read the low halves of the operands, the upper one negated: the widening costs no instruction.
+__device__ __forceinline__ uint32_t pkf_max_raw(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_max_f16 %0, %1, %2 op_sel_hi:[0,0] neg_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t pkf_min_raw(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_min_f16 %0, %1, %2 op_sel_hi:[0,0] neg_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
-#define ARC_BIAS 0x400  // added to both halves of a widened ring pixel (see pk_max3)
-
-// t points at the centre byte of the staged tile.  Ring bytes are widened to p | (255-p)<<16 (plus ARC_BIAS in
-// both halves): max over a 9-arc of the low halves = brightest ring pixel of the arc, of the high halves =
-// 255 - darkest.  Both polarities at once:
+// t points at the centre byte of the staged tile.  Both polarities at once, the bright side in the low halves
+// and the dark side, negated, in the high halves (see above):
 //   dark   (ring < v):  max_arcs min(v - ring) = v - min_arcs max_9(ring)
-//   bright (ring > v):  max_arcs min(ring - v) = (255 - min_arcs max_9(255 - ring)) - v
+//   bright (ring > v):  max_arcs min(ring - v) = max_arcs min_9(ring) - v = -min_arcs max_9(-ring) - v
 __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
 {
     const int p = IMG_W;
@@ -119,10 +134,6 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
     d[13] = t[p - 3];
     d[14] = t[2 * p - 2];
     d[15] = t[3 * p - 1];
-    // p -> p | (255-p) << 16, biased, in one 24-bit multiply-add: p * (1 - 65536) + (255 << 16) + bias
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        d[k] = (uint32_t)(__mul24((int)d[k], -65535) + (0x00ff0000 + ARC_BIAS * 0x10001));
     // Arc k holds ring pixels k .. k+8.  Arcs k and k-1 share the eight pixels k .. k+7, so
     //   min(max_arc(k), max_arc(k-1)) = max(max8(k), min(d[k+8], d[k-1]))
     // and the even k cover all sixteen arcs: the eight-pixel maxima are needed at even k only, and each joins
@@ -130,17 +141,17 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
     uint32_t m2[8], m4[8], x[8];
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        m2[k] = pk_max(d[2 * k], d[2 * k + 1]);
+        m2[k] = pkf_max_raw(d[2 * k], d[2 * k + 1]);
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        m4[k] = pk_max(m2[k], m2[(k + 1) & 7]);
+        m4[k] = pkf_max(m2[k], m2[(k + 1) & 7]);
 #pragma unroll
     for (int k = 0; k < 8; k++)  // pixels 2k .. 2k+7 and the outer pair
-        x[k] = pk_max3(m4[k], m4[(k + 2) & 7], pk_min(d[(2 * k + 8) & 15], d[(2 * k + 15) & 15]));
-    const uint32_t best = pk_min(pk_min3(pk_min3(x[0], x[1], x[2]), x[3], x[4]), pk_min3(x[5], x[6], x[7]));
+        x[k] = pkf_max3(m4[k], m4[(k + 2) & 7], pkf_min_raw(d[(2 * k + 8) & 15], d[(2 * k + 15) & 15]));
+    const uint32_t best = pkf_min(pkf_min3(pkf_min3(x[0], x[1], x[2]), x[3], x[4]), pkf_min3(x[5], x[6], x[7]));
     const int v = t[0];
-    const int dark = v + ARC_BIAS - (int)(best & 0xffff);
-    const int bright = 255 + ARC_BIAS - (int)(best >> 16) - v;
+    const int dark = v - (int)(best & 0xffff);                // v - min_arcs max_9(ring)
+    const int bright = (int)((best >> 16) & 0x7fff) - v;      // max_arcs min_9(ring) - v
     return max(dark, bright);
 }
 
@@ -196,7 +207,6 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     const uint8_t *src = lvl == 0 ? a.l0.ptr + (size_t)f * a.l0.fstride : pyr + (size_t)f * a.slab + a.off[lvl];
     const int lane = threadIdx.x & 63;
     uint32_t *img32 = reinterpret_cast<uint32_t *>(img);
-    uint32_t *sc32 = reinterpret_cast<uint32_t *>(sc);
 
     if (threadIdx.x == 0)
         qn = 0, sn = 0, cn = 0;
@@ -209,6 +219,14 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     const bool aligned = (pitch & 15) == 0 && ((uintptr_t)src & 15) == 0;
     const int nrows = min(IMG_H, y_hi + 3 - (ty0 - 4));                       // staged rows 0 .. nrows-1
     const int npieces = min(IMG_W / 16, (pitch - (tx0 - IMG_X0)) >> 4);        // pieces 0 .. npieces-1 of a row
+    // the score map starts at zero: 297 pieces of 16 bytes
+    static_assert(SC_H * SC_P % 16 == 0 && SC_H * SC_P / 16 <= 512, "two pieces per thread cover the score map");
+    auto zero_scores = [&]() {
+        uint4 *z = reinterpret_cast<uint4 *>(sc);
+        z[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        if (threadIdx.x + 256 < SC_H * SC_P / 16)
+            z[threadIdx.x + 256] = make_uint4(0u, 0u, 0u, 0u);
+    };
     if (aligned) {
         const uint8_t *s0 = src + (size_t)(ty0 - 4) * pitch + (tx0 - IMG_X0);
         // both loads of a thread are in flight before its first LDS store
@@ -222,11 +240,14 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
             va = *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(ra, pitch) + 16 * ca));
         if (okb)
             vb = *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(rb, pitch) + 16 * cb));
+        zero_scores();  // (while the loads are in flight)
         if (oka)
             *reinterpret_cast<uint4 *>(&img[ra * IMG_W + 16 * ca]) = va;
         if (okb)
             *reinterpret_cast<uint4 *>(&img[rb * IMG_W + 16 * cb]) = vb;
-    } else if (walker) {
+    } else {
+        zero_scores();
+        if (walker) {
         const int x = tx0 - 4 + 4 * g;
         for (int r = r0; r < IMG_H; r += 14) {
             const int y = ty0 - 4 + r;
@@ -235,6 +256,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
                 v = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(__umul24(y, pitch) + x));
             img32[r * IMG_WORDS + GRP_0 + g] = v;
         }
+        }
     }
     __syncthreads();
     FAST_CUT(1);
@@ -242,36 +264,36 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     // ---- compass test, four pixels per thread, on staged rows 3..68 (tile rows -1..64) ----
     const int tm = a.t_low;
     const uint32_t qt4 = (uint32_t)min((tm + 1) >> 1, 127) * 0x01010101u;
-    // the whole score region lies in the detectable range for tiles away from the image border
-    const bool all_valid = tx0 - 1 >= x_lo && tx0 + ORBX_FAST_W + 1 <= x_hi && ty0 - 1 >= y_lo &&
-                           ty0 + ORBX_FAST_H + 1 <= y_hi;
     {
         // bit 7 of byte o of a pass word stands for pixel o of the group; the groups left and right
         // of the tile hold one needed pixel each
         const int xg = tx0 - 4 + 4 * g;
         uint32_t gmask = !walker ? 0u : g == 0 ? 0x80000000u : g == GRP_W - 1 ? 0x00000080u : 0x80808080u;
-        if (!all_valid) {
+        if (tx0 - 1 < x_lo || tx0 + ORBX_FAST_W + 1 > x_hi) {  // (uniform) a tile at the left or right border
 #pragma unroll
             for (int o = 0; o < 4; o++)
                 if (xg + o < x_lo || xg + o >= x_hi)
                     gmask &= ~(0x80u << (8 * o));
         }
+        // Score rows 0 .. lim-1 (staged rows 3 ..) hold detectable pixels; above the first of them lies an
+        // undetectable one only in the tiles of the top row, whose ring row it is.  Trip k takes score row
+        // r0 + 14 k: one comparison per trip, and every address is a constant away from the first trip's.
+        static_assert(ORBX_FAST_Y0 == ORBX_CELL_ORG, "the tile grid starts at the first detectable row");
+        const int lim = min(SC_H, y_hi - (ty0 - 1));
+        const uint32_t gmask0 = (ty0 - 1 < y_lo && r0 == 0) ? 0u : gmask;
+        const uint32_t *wrow0 = img32 + (r0 + 3) * IMG_WORDS + GRP_0 + g;
         // Pass bits of the five trips collect in one word: trip k's bits (7, 15, 23, 31) move down by k.
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) {
-            const int r = r0 + 3 + 14 * k;
-            const int y = ty0 - 4 + r;
-            if (walker && r < 3 + SC_H) {
-                const uint32_t *wrow = img32 + r * IMG_WORDS + GRP_0 + g;
-                sc32[(r - 3) * (SC_P / 4) + g] = 0u;
-                if (gmask != 0u && (all_valid || (y >= y_lo && y < y_hi))) {
-                    const uint32_t vw = wrow[0], upw = wrow[-3 * IMG_WORDS], dnw = wrow[3 * IMG_WORDS];
-                    const uint32_t lw = wrow[-1], rw = wrow[1];
-                    const uint32_t r4w = __builtin_amdgcn_alignbyte(rw, vw, 3);   // pixels x+3
-                    const uint32_t r12w = __builtin_amdgcn_alignbyte(vw, lw, 1);  // pixels x-3
-                    acc |= (compass4(vw, dnw, upw, r4w, r12w, qt4) & gmask) >> k;
-                }
+            const uint32_t gm = k == 0 ? gmask0 : gmask;
+            if (gm != 0u && r0 < lim - 14 * k) {
+                const uint32_t *wrow = wrow0 + 14 * k * IMG_WORDS;
+                const uint32_t vw = wrow[0], upw = wrow[-3 * IMG_WORDS], dnw = wrow[3 * IMG_WORDS];
+                const uint32_t lw = wrow[-1], rw = wrow[1];
+                const uint32_t r4w = __builtin_amdgcn_alignbyte(rw, vw, 3);   // pixels x+3
+                const uint32_t r12w = __builtin_amdgcn_alignbyte(vw, lw, 1);  // pixels x-3
+                acc |= (compass4(vw, dnw, upw, r4w, r12w, qt4) & gm) >> k;
             }
         }
         // queue slots: a wave-wide prefix sum of the per-lane counts, one LDS atomic per wave
