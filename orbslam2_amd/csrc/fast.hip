@@ -46,22 +46,23 @@
 //     r < v - t  =>  q(r) <= q(v) - qt        r > v + t  =>  q(r) >= q(v) + qt
 // (checked for every v, r and t), so the halved test passes every pixel the exact one passes and about 3 %
 // more; it only selects the pixels whose exact score is computed.  Bytes never borrow from or carry into
-// their neighbours: (0x80 | a) - b and a + (0x80 - b) stay inside 1 .. 255 for 7-bit a and b, and their top
-// bit is a >= b.  All of it is 32-bit add / subtract / logic, which this chip issues at twice the rate of
-// the packed 16-bit minimum / maximum instructions.  Returns the pass bits in bit 7 of each byte.
+// their neighbours: every minuend has its top bit set and every subtrahend is a 7-bit value, and the top bit
+// of a difference is the comparison.  Where q(v) - qt < 0 or q(v) + qt > 127 no ring pixel can pass; there the
+// low bits of x and z below are meaningless, and their top bits, which say so, mask the result.  All of it is
+// 32-bit add / subtract / logic, which this chip issues at twice the rate of the packed 16-bit minimum /
+// maximum instructions.  Returns the pass bits in bit 7 of each byte.
 __device__ __forceinline__ uint32_t compass4(uint32_t vw, uint32_t r0w, uint32_t r8w, uint32_t r4w, uint32_t r12w,
                                              uint32_t qt4)
 {
     const uint32_t H = 0x80808080u, L7 = 0x7f7f7f7fu;
-    const uint32_t qv = (vw >> 1) & L7, q0 = (r0w >> 1) & L7, q8 = (r8w >> 1) & L7, q4 = (r4w >> 1) & L7,
+    const uint32_t hv = vw >> 1, q0 = (r0w >> 1) & L7, q8 = (r8w >> 1) & L7, q4 = (r4w >> 1) & L7,
                    q12 = (r12w >> 1) & L7;
-    // lo = max(qv - qt, 0) with the top bit set; c = 0x80 - min(qv + qt, 127)
-    const uint32_t x = (qv | H) - qt4, xm = x & H;
-    const uint32_t lo = (x & (xm - (xm >> 7))) | H;
-    const uint32_t s = qv + qt4, sm = s & H;
-    const uint32_t c = H - ((s | (sm - (sm >> 7))) & L7);
-    const uint32_t dark = ((lo - q0) | (lo - q8)) & ((lo - q4) | (lo - q12));
-    const uint32_t bright = ((q0 + c) | (q8 + c)) & ((q4 + c) | (q12 + c));
+    const uint32_t x = (hv | H) - qt4;   // top bit: q(v) >= qt; then the low bits are q(v) - qt
+    const uint32_t z = (~hv | H) - qt4;  // top bit: q(v) + qt <= 127; then the low bits are 127 - q(v) - qt
+    const uint32_t lo = x | H;           // lo - q has its top bit set iff q <= q(v) - qt
+    const uint32_t c = (z | H) - L7;     // 128 - q(v) - qt: q + c has its top bit set iff q >= q(v) + qt
+    const uint32_t dark = ((lo - q0) | (lo - q8)) & ((lo - q4) | (lo - q12)) & x;
+    const uint32_t bright = ((q0 + c) | (q8 + c)) & ((q4 + c) | (q12 + c)) & z;
     return dark | bright;
 }
 
