@@ -49,7 +49,8 @@ def main():
         "kernel", "launches", "FETCH KiB", "WRITE KiB", "HBM MB", "VALU instr", "SALU instr", "LDS instr"))
     kernels = {}
     for k in ("k_resize", "k_fast", "k_octree", "k_blur", "k_describe"):
-        per_batch = 7 if k == "k_resize" else 1  # launches per batch (one resize per level above 0)
+        # launches per batch: one resize per level above 0, two quadtree launches (large and small levels), one else
+        per_batch = max(1, round(len(sq[k]["SQ_INSTS_VALU"]) / len(sq["k_fast"]["SQ_INSTS_VALU"])))
         f = mean(fetch[k]["FETCH_SIZE"]) * per_batch
         w = mean(write[k]["WRITE_SIZE"]) * per_batch
         hbm = (2 * f + w) * 1024
@@ -65,7 +66,7 @@ def main():
     if os.path.isdir(l1dir):
         l1 = load(l1dir)
         lines.append("")
-        lines.append("vector memory path per launch (TA_TA_BUSY summed over the 256 compute units, GRBM_GUI_ACTIVE over the 8 XCDs):")
+        lines.append("vector memory path per launch (an average over the launches of a kernel; TA_TA_BUSY summed over the 256 compute units, GRBM_GUI_ACTIVE over the 8 XCDs):")
         lines.append("%-11s %14s %16s %16s %16s %10s" % (
             "kernel", "TA busy cyc", "L1 accesses", "L1->L2 reads", "pending stall", "TA busy"))
         for k in ("k_resize", "k_fast", "k_octree", "k_blur", "k_describe"):
@@ -80,7 +81,7 @@ def main():
     if os.path.isdir(ldsdir):
         ld = load(ldsdir)
         lines.append("")
-        lines.append("LDS per launch (SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT: cycles summed over the 256 compute units; "
+        lines.append("LDS per launch (an average over the launches of a kernel; SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT: cycles summed over the 256 compute units; "
                      "SQ_BUSY_CYCLES over the 32 shader engines):")
         lines.append("%-11s %14s %16s %12s %18s" % ("kernel", "LDS instr", "LDS active cyc", "conflict", "LDS busy of time"))
         for k in ("k_fast", "k_octree", "k_blur", "k_describe"):
