@@ -357,23 +357,25 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     // them per launch) and writes the records.  The arrays are filled in no particular order; every candidate
     // carries its order key, which is all the quadtree needs.
     const uint32_t wc_magic = a.wc_magic[lvl], hc_magic = a.hc_magic[lvl];
+    // All eight neighbours are read (the score map has a one-pixel ring); those of another cell are masked out
+    // by the pixel's position inside its cell, without branches.
+    const uint32_t wcu = (uint32_t)wc, hcu = (uint32_t)hc;
     auto is_maximum = [&](int e) -> bool {
         const int r = e >> 7, c = e & 127;
         const uint8_t *p = &sc[SC_AT(r, c)];
-        const int A = p[0];
-        const int y = ty0 - 4 + r, x = tx0 - IMG_X0 + c;
         // x - 19 < 4096 and cells are 30 .. 60 pixels: the 20-bit reciprocal divides exactly
-        const int cj = (int)(((uint32_t)(x - ORBX_CELL_ORG) * wc_magic) >> 20);
-        const int ci = (int)(((uint32_t)(y - ORBX_CELL_ORG) * hc_magic) >> 20);
-        const int cx0 = ORBX_CELL_ORG + cj * wc, cy0 = ORBX_CELL_ORG + ci * hc;
-        const bool l = x - 1 >= cx0, rr = x + 1 < cx0 + wc;
-        const bool u = y - 1 >= cy0, dn = y + 1 < cy0 + hc;
-        const int nl = l ? p[-1] : 0, nr = rr ? p[1] : 0;
-        const int ul = l ? p[-SC_P - 1] : 0, uc = p[-SC_P], ur = rr ? p[-SC_P + 1] : 0;
-        const int dl = l ? p[SC_P - 1] : 0, dc = p[SC_P], dr = rr ? p[SC_P + 1] : 0;
-        const int mu = u ? max(max(ul, uc), ur) : 0, md = dn ? max(max(dl, dc), dr) : 0;
-        const int m = max(max(nl, nr), max(mu, md));
-        return A > m;
+        const uint32_t ux = (uint32_t)(tx0 - IMG_X0 - ORBX_CELL_ORG + c), uy = (uint32_t)(ty0 - 4 - ORBX_CELL_ORG + r);
+        const uint32_t xm = ux - __umul24(__umul24(ux, wc_magic) >> 20, wcu);  // column and row inside the cell
+        const uint32_t ym = uy - __umul24(__umul24(uy, hc_magic) >> 20, hcu);
+        const uint32_t A = p[0], nl = p[-1], nr = p[1];
+        const uint32_t ul = p[-SC_P - 1], uc = p[-SC_P], ur = p[-SC_P + 1];
+        const uint32_t dl = p[SC_P - 1], dc = p[SC_P], dr = p[SC_P + 1];
+        const uint32_t ml = xm != 0u ? ~0u : 0u, mr = xm != wcu - 1u ? ~0u : 0u;
+        const uint32_t mu = ym != 0u ? ~0u : 0u, md = ym != hcu - 1u ? ~0u : 0u;
+        const uint32_t left = max(max(ul & mu, nl), dl & md) & ml;
+        const uint32_t right = max(max(ur & mu, nr), dr & md) & mr;
+        const uint32_t mid = max(uc & mu, dc & md);
+        return A > max(max(left, right), mid);
     };
     auto list_survivors = [&](bool have, int e) {
         const bool keep = have && is_maximum(e);
