@@ -236,16 +236,17 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         const int ra = (int)(__umul24(threadIdx.x, 10923u) >> 16), ca = (int)threadIdx.x - 6 * ra;
         const int rb = ra + (ca >= 2 ? 43 : 42), cb = ca >= 2 ? ca - 2 : ca + 4;
         const bool oka = ra < nrows && ca < npieces, okb = rb < nrows && cb < npieces;
-        uint4 va = make_uint4(0u, 0u, 0u, 0u), vb = va;
+        // straight from global memory into LDS: item i of the tile lands at byte 16 i of img, i.e. at 16 bytes per
+        // lane from the wave's base, which is where this load instruction puts a lane's piece
+        typedef __attribute__((address_space(1))) const void gvoid;
+        typedef __attribute__((address_space(3))) void lvoid;
+        uint8_t *wbase = img + (threadIdx.x >> 6) * (64 * 16);
         if (oka)
-            va = *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(ra, pitch) + 16 * ca));
+            __builtin_amdgcn_global_load_lds((gvoid *)(s0 + (uint32_t)(__umul24(ra, pitch) + 16 * ca)), (lvoid *)wbase, 16, 0, 0);
         if (okb)
-            vb = *reinterpret_cast<const uint4 *>(s0 + (uint32_t)(__umul24(rb, pitch) + 16 * cb));
-        zero_scores();  // (while the loads are in flight)
-        if (oka)
-            *reinterpret_cast<uint4 *>(&img[ra * IMG_W + 16 * ca]) = va;
-        if (okb)
-            *reinterpret_cast<uint4 *>(&img[rb * IMG_W + 16 * cb]) = vb;
+            __builtin_amdgcn_global_load_lds((gvoid *)(s0 + (uint32_t)(__umul24(rb, pitch) + 16 * cb)),
+                                             (lvoid *)(wbase + 256 * 16), 16, 0, 0);
+        zero_scores();
     } else {
         zero_scores();
         if (walker) {
