@@ -57,7 +57,11 @@ struct BlurFetch {
 // right of it byte by byte.  Nearly half of the tiles of a pyramid touch a border, so they must not cost more
 // than this.  A tile at the bottom of a level holds h - ty0 < 32 rows: only the row pairs those rows read are staged.
 // blur_stage_fetch issues the loads (aligned levels; an unaligned level is read in blur_stage_commit).
-__device__ __forceinline__ void blur_stage_fetch(const BlurTile &t, BlurFetch &fx)
+// Direct: whole pieces go straight from global memory into `img` (a load that writes LDS puts a lane's 16 bytes
+// at 16 bytes per lane from a wave-uniform base, and item i of a tile belongs at byte 16 i of the staged tile);
+// only for kernels that stage one tile per workgroup, where `img` is free when the fetch is issued.
+template <bool Direct = false>
+__device__ __forceinline__ void blur_stage_fetch(const BlurTile &t, BlurFetch &fx, uint32_t *img = nullptr)
 {
     if (!t.aligned())
         return;
@@ -79,7 +83,16 @@ __device__ __forceinline__ void blur_stage_fetch(const BlurTile &t, BlurFetch &f
             const int sy = interior ? t.ty0 - 3 + r : reflect101(t.ty0 - 3 + r, t.h);
             const uint32_t o = (uint32_t)(__umul24(sy, t.spitch) + x0);
             if (interior || o + 16u <= src_bytes) {
-                fx.v[k] = *reinterpret_cast<const uint4 *>(t.src + o);
+                if (Direct) {
+                    static_assert(BL_SWORDS * 4 % 16 == 0, "staged rows are whole 16-byte pieces");
+                    typedef __attribute__((address_space(1))) const void gvoid;
+                    typedef __attribute__((address_space(3))) void lvoid;
+                    uint8_t *wbase = reinterpret_cast<uint8_t *>(img) + ((threadIdx.x >> 6) * 64 + 256 * k) * 16;
+                    __builtin_amdgcn_global_load_lds((gvoid *)(t.src + o), (lvoid *)wbase, 16, 0, 0);
+                    fx.dst[k] = -1;  // nothing left to commit
+                } else {
+                    fx.v[k] = *reinterpret_cast<const uint4 *>(t.src + o);
+                }
             } else {
                 // the last pieces of the last row: pixels only
                 uint32_t q[4] = {0, 0, 0, 0};

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     int lvl_next = 0;
     BlurTile next = tile_of(unit0, lvl_next);
     BlurFetch fx;
-    blur_stage_fetch(next, fx);
+    blur_stage_fetch<BLUR_TPW == 1>(next, fx, img);
     for (int tile = 0; tile < nunits; tile++) {
     const BlurTile cur = next;
     const int lvl = lvl_next;
