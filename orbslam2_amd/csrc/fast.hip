@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
         }
     }
     __syncthreads();
+    FAST_CUT(4);
     // the first wave alone writes the records (a tile keeps about 45 candidates): no second barrier, and the
     // other waves retire
     const int ns = sn;

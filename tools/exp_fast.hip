@@ -114,12 +114,13 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const char *names[] = {"cut at the first statement", "cut before staging (tile found)", "cut after staging",
-                           "cut after compass test + queue", "cut after arc score", "whole kernel"};
-    float tt[6];
-    long long ff[6];
+                           "cut after compass test + queue", "cut after arc score", "cut after suppression",
+                           "whole kernel"};
+    float tt[7];
+    long long ff[7];
     float *t = tt + 1;
     long long *found = ff + 1;
-    for (int cut = -1; cut <= 4; cut++) {
+    for (int cut = -1; cut <= 5; cut++) {
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_fast_cut), &cut, 4));
         for (int r = 0; r < 3; r++)
             k_fast<<<grid, 256>>>(d_pyr, d_cnt, d_xy, d_resp, d_key, d_flag, d_status, d_tab, a);
@@ -140,7 +141,7 @@ int main(int argc, char **argv)
             found[cut] += c;
     }
     printf("%d frames, %d tiles per frame\n", B, tiles);
-    for (int cut = -1; cut <= 4; cut++)
+    for (int cut = -1; cut <= 5; cut++)
         printf("  %-34s %.4f ms   (%.1f candidates per frame)\n", names[cut + 1], t[cut], (double)found[cut] / B);
     orbx_extractor_destroy(ex);
     return 0;
