@@ -16,7 +16,7 @@
 // reference appends them.
 //
 // Work per 64x64 tile:  stage the image tile (+4 px) in LDS; test every pixel of the tile (+1 px
-// ring) against the four compass points, two pixels per packed 16-bit operation (a 9-arc contains at
+// ring) against the four compass points, four pixels per 32-bit operation (a 9-arc contains at
 // least one pixel of each antipodal pair); queue the few that pass; compute A only for those, both
 // polarities at once with packed 16-bit min/max (half-precision instructions on values whose float order is their
 // integer order: they have three-input forms and operand modifiers that widen the bytes for free); suppress
@@ -111,8 +111,8 @@ __device__ __forceinline__ uint32_t pkf_min_raw(uint32_t a, uint32_t b)
     return d;
 }
 
-// t points at the centre byte of the staged tile.  Both polarities at once, the bright side in the low halves
-// and the dark side, negated, in the high halves (see above):
+// t points at the centre byte of the staged tile.  Both polarities at once: the low halves carry maxima of ring
+// pixels (the dark test), the high halves minima of ring pixels, negated (the bright test; see above):
 //   dark   (ring < v):  max_arcs min(v - ring) = v - min_arcs max_9(ring)
 //   bright (ring > v):  max_arcs min(ring - v) = max_arcs min_9(ring) - v = -min_arcs max_9(-ring) - v
 __device__ __forceinline__ int fast_arc_score(const uint8_t *t)
