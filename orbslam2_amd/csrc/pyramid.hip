@@ -192,12 +192,17 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void k_resize(const uint8_t *__restrict__ src_lvl, long long src_fstride,
                                                 uint32_t src_bytes, uint8_t *__restrict__ pyr_out, int slab, int spitch,
                                                 int doff, int dpitch, int dw, int dh,
-                                                const OrbxXCoef *__restrict__ xt, const OrbxYCoef *__restrict__ yt)
+                                                const OrbxXCoef *__restrict__ xt, const OrbxYCoef *__restrict__ yt, int batch,
+                                                int fshift)
 {
-    const int f = blockIdx.z;
+    // blockIdx.x = column block << fshift | frame inside its group of 1 << fshift frames: workgroups are handed to
+    // the XCDs in turn, so with groups of 8 every workgroup of a frame runs on the same XCD and the source lines that
+    // neighbouring column blocks share (a block's 307 source bytes touch three or four 128-byte lines) are fetched
+    // into one L2 once instead of into two
+    const int f = (int)(blockIdx.z << fshift) + (int)(blockIdx.x & ((1u << fshift) - 1u));
     const int dy0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.y * 4 + (threadIdx.x >> 6)) * ROWS);
-    const int dx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    if (dy0 >= dh || dx0 >= dw)
+    const int dx0 = ((blockIdx.x >> fshift) * 64 + (threadIdx.x & 63)) * 4;
+    if (dy0 >= dh || dx0 >= dw || f >= batch)
         return;
     uint8_t *dbase = pyr_out + (size_t)f * slab + doff;
     resize_rows<ROWS>(src_lvl + (size_t)f * src_fstride, spitch, src_bytes, dx0, dy0, min(dy0 + ROWS, dh), xt, yt,
@@ -288,7 +293,8 @@ hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b
     const OrbxLevel &D = g.lv[level];
     // a few frames do not fill the machine: the shorter strips give twice the waves
     const int rows = g.batch >= 32 ? RS_ROWS : RS2_ROWS;
-    dim3 grid((D.w + 255) / 256, (D.h + 4 * rows - 1) / (4 * rows), g.batch);
+    const int fshift = g.batch >= 8 ? 3 : 0;
+    dim3 grid(((D.w + 255) / 256) << fshift, (D.h + 4 * rows - 1) / (4 * rows), (g.batch + (1 << fshift) - 1) >> fshift);
     const uint8_t *src = level == 1 ? b.l0.ptr : b.pyr + S.off;
     const long long sfs = level == 1 ? b.l0.fstride : (long long)g.slab;
     const int spitch = level == 1 ? b.l0.pitch : S.pitch;
@@ -297,9 +303,9 @@ hipError_t orbx_launch_resize(int level, const OrbxGeom &g, const OrbxBuffers &b
     const uint32_t src_bytes = (uint32_t)spitch * (uint32_t)S.h + (level == 1 ? 0u : 16u);
     if (rows == RS_ROWS)
         k_resize<RS_ROWS><<<grid, 256, 0, s>>>(src, sfs, src_bytes, b.pyr, g.slab, spitch, D.off, D.pitch, D.w, D.h,
-                                               b.xtab + D.xtab_off, b.ytab + D.ytab_off);
+                                               b.xtab + D.xtab_off, b.ytab + D.ytab_off, g.batch, fshift);
     else
         k_resize<RS2_ROWS><<<grid, 256, 0, s>>>(src, sfs, src_bytes, b.pyr, g.slab, spitch, D.off, D.pitch, D.w, D.h,
-                                                b.xtab + D.xtab_off, b.ytab + D.ytab_off);
+                                                b.xtab + D.xtab_off, b.ytab + D.ytab_off, g.batch, fshift);
     return hipGetLastError();
 }
