@@ -26,7 +26,8 @@ struct OctLevel {
 struct OctArgs {
     int nlevels, cand_per_frame, kp_per_frame, cells_per_frame;
     int t_ini, t_min;  // FAST thresholds clamped to [1,255]
-    int level0;        // first level of this launch (blockIdx.x counts from it)
+    int level0;        // first level of this launch (the block's unit counts from it)
+    int batch;
     OctLevel lv[ORBX_MAX_LEVELS];
 };
 
@@ -540,7 +541,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                 uint8_t *__restrict__ kept_resp, int *__restrict__ nkept,
                                                 int *__restrict__ status, OctArgs a)
 {
-    const int lvl = blockIdx.x + a.level0, f = blockIdx.y;
+    // a frame's workgroups run on the XCD whose L2 holds the frame's candidates (written there by the detection kernel)
+    const int lvl = ORBX_BLOCK_UNIT + a.level0, f = ORBX_BLOCK_FRAME;
+    if (f >= a.batch)
+        return;
     const OctLevel &L = a.lv[lvl];
     const size_t cb = (size_t)f * a.cand_per_frame + L.cand_base;
     const size_t kb = (size_t)f * a.kp_per_frame + L.kp_base;
@@ -580,7 +584,8 @@ hipError_t orbx_launch_octree(const OrbxGeom &g, const OrbxBuffers &b, hipStream
                 return e;
         }
         a.level0 = l0;
-        kernel<<<dim3(l1 - l0, g.batch), nt, lds, s>>>(b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.cand_node,
+        a.batch = g.batch;
+        kernel<<<orbx_frame_grid(l1 - l0, g.batch), nt, lds, s>>>(b.cand_xy, b.cand_resp, b.cand_key, b.cell_flag, b.cand_node,
                                                        b.ncand, b.kept_xy, b.kept_resp, b.nkept, b.status, a);
         return hipGetLastError();
     };
