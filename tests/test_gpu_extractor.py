@@ -156,6 +156,32 @@ def test_batch_matches_single(oracle):
         compare_frame(kg, dg, ko, do)
 
 
+@pytest.mark.parametrize("w,h,B", [(402, 301, 40), (1241, 376, 33)])
+def test_batch_of_thirty_two_or_more(oracle, w, h, B):
+    """Batches of 32 frames or more take kernels of their own (16 destination rows per wave in the resize, a
+    frame's workgroups on one XCD, the quadtree in two launches): every frame, also those of the incomplete last
+    group of eight, must equal the oracle, and the pyramid of one of them bit for bit."""
+    rng = np.random.default_rng(B)
+    imgs = []
+    for i in range(B):
+        if i % 11 == 5:
+            imgs.append((128 + rng.integers(-40, 41, size=(h, w))).clip(0, 255).astype(np.uint8))
+        else:
+            imgs.append(orbx.synth_image(SEED + 31 * i, w, h, 0 if i % 4 else 2))
+    ex = make_extractor(KITTI, w, h, batch=B)
+    ex.extract_batch_host(imgs)
+    n, _ = ex.batch_counts()
+    step = 1 if w < 1000 else 4  # (the oracle takes 35 ms for a frame of the larger size)
+    for i in list(range(0, B, step)) + [B - 1]:
+        kg, dg = ex.batch_download(i)
+        ko, do, tr = oracle_extract(oracle, imgs[i], KITTI, trace=True)
+        assert n[i] == len(ko)
+        compare_frame(kg, dg, ko, do)
+        if i == B - 1:
+            for lvl in range(KITTI["nlevels"]):
+                assert np.array_equal(ex.pyramid_level(i, lvl), tr["levels"][lvl]), lvl
+
+
 def test_batch_of_ten_with_crowded_levels(oracle):
     """Ten frames in one batch, some with so many candidates (white noise) that a level's candidates no longer
     fit the registers of the distribution kernel's threads: each must equal the oracle, and the same frame
