@@ -230,7 +230,6 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
     };
     if (aligned) {
         const uint8_t *s0 = src + (size_t)(ty0 - 4) * pitch + (tx0 - IMG_X0);
-        // both loads of a thread are in flight before its first LDS store
         // 72 rows x 6 pieces = 432 items; a thread takes items i and i + 256 (256 = 42 * 6 + 4)
         static_assert(IMG_W / 16 == 6, "the item arithmetic below is for six pieces per row");
         const int ra = (int)(__umul24(threadIdx.x, 10923u) >> 16), ca = (int)threadIdx.x - 6 * ra;
@@ -248,16 +247,17 @@ __global__ __launch_bounds__(256) void k_fast(const uint8_t *__restrict__ pyr, i
                                              (lvoid *)(wbase + 256 * 16), 16, 0, 0);
         zero_scores();
     } else {
+        // a level at an odd address or pitch (a caller's frame): word by word, the 18 words of a row that matter
         zero_scores();
         if (walker) {
-        const int x = tx0 - 4 + 4 * g;
-        for (int r = r0; r < IMG_H; r += 14) {
-            const int y = ty0 - 4 + r;
-            uint32_t v = 0;
-            if (y >= 0 && y < h && x >= 0 && x < pitch)
-                v = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(__umul24(y, pitch) + x));
-            img32[r * IMG_WORDS + GRP_0 + g] = v;
-        }
+            const int x = tx0 - 4 + 4 * g;
+            for (int r = r0; r < IMG_H; r += 14) {
+                const int y = ty0 - 4 + r;
+                uint32_t v = 0;
+                if (y >= 0 && y < h && x >= 0 && x < pitch)
+                    v = *reinterpret_cast<const uint32_t *>(src + (uint32_t)(__umul24(y, pitch) + x));
+                img32[r * IMG_WORDS + GRP_0 + g] = v;
+            }
         }
     }
     __syncthreads();
